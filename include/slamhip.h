@@ -1,0 +1,135 @@
+/*
+ * slamhip.h -- C ABI of libslamhip.so: the MI355X (gfx950) implementation of
+ * SLAM channelfit's inner likelihood loop, batched over emcee walkers.
+ *
+ * The reference (jinshisai/SLAM) is pure Python and has no FFI of its own; the
+ * de-facto boundary this library sits behind is
+ *
+ *   - the per-walker closure `lnprob(p)`      channelfit/_channelfit.py:594-603
+ *   - the public method `ChannelFit.cubemodel` channelfit/_channelfit.py:499-537
+ *
+ * Each entry point below names the reference code it replaces.  Everything is
+ * plain C: opaque handle, caller-owned row-major float64 arrays, `int` status
+ * (0 = ok, <0 = error; text via slamhip_last_error).  No exceptions cross the
+ * boundary.  One context drives ONE GPU (the current HIP device at create
+ * time); multi-GPU use is one process per GPU, each with its own context and
+ * its own shard of the walkers (walkers are independent -- no collective on the
+ * data path).
+ *
+ * Parameter vectors are always 13 float64 in the reference's positional order
+ * (_channelfit.py:219-221), natural units (NOT log10):
+ *   Mstar, Rc, cs, h1, h2, pI, Rin, Ienv, xoff, yoff, voff, incloff, paoff
+ */
+#ifndef SLAMHIP_H
+#define SLAMHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SLAMHIP_NPARAM 13
+#define SLAMHIP_PROF_LEN 45 /* _channelfit.py:419: 2*int(2*11)+1 */
+
+enum {
+  SLAMHIP_OK = 0,
+  SLAMHIP_ERR_ARG = -1,    /* bad descriptor / argument                  */
+  SLAMHIP_ERR_HIP = -2,    /* a HIP runtime call failed                  */
+  SLAMHIP_ERR_NOMEM = -3,  /* device allocation failed                   */
+  SLAMHIP_ERR_STATE = -4   /* context unusable                           */
+};
+
+/* Everything `ChannelFit.makegrid` derives once per fit
+ * (_channelfit.py:227-341).  All pointers are HOST pointers, copied to the GPU
+ * by slamhip_create; the caller may free them afterwards. */
+typedef struct slamhip_desc {
+  int32_t nv;        /* len(v_valid)                                :270 */
+  int32_t ny, nx;    /* observed cube, data_valid[nv][ny][nx]       :272-274 */
+  int32_t nlayer;    /* nested-grid layers                          :298 */
+  int32_t npix;      /* nested-grid side, multiple of 4             :294-295 */
+  int32_t nq1, nq3;  /* inner quadrant [nq1,nq3) of each layer      :296-297 */
+  int32_t ineed0, ineed1; /* layer-0 crop [ineed0,ineed1)           :337-339 */
+  int32_t kbeam;     /* beam kernel side K = 2*ngauss+1             :329-333 */
+  int32_t disk;      /* class flag `disk`                           :222 */
+  int32_t envelope;  /* class flag `envelope`                       :223 */
+  double dv;         /* channel width (may be < 0)           utils.py:262 */
+  double sigma;      /* noise rms                                   :602 */
+  double pixperbeam; /* sum(gaussbeam)                              :334 */
+  double incl0;      /* inclination [deg]                           :258 */
+  double signmajor, signminor; /* +-1                               :282-289 */
+  double vunit;      /* sqrt(G Msun / au) [km/s]                    :29-32 */
+  const double* Xnest0; /* [nlayer][npix][npix]                     :318-320 */
+  const double* Ynest0; /* [nlayer][npix][npix]                            */
+  const double* xneed;  /* [ineed1-ineed0] ascending                :340 */
+  const double* yneed;  /* [ineed1-ineed0] ascending                :341 */
+  const double* xobs;   /* [nx] observed x (usually descending)     :263 */
+  const double* yobs;   /* [ny] observed y                          :263 */
+  const double* v_valid;    /* [nv]                                 :270 */
+  const double* data_valid; /* [nv][ny][nx]                         :274 */
+  const double* gaussbeam;  /* [kbeam][kbeam], not normalised       :333 */
+  int64_t max_scratch_bytes; /* cap on per-batch device scratch; 0 = default */
+} slamhip_desc;
+
+typedef struct slamhip_ctx slamhip_ctx;
+
+/* Replaces the state `makegrid` leaves on `self` (:227-341): uploads the
+ * constants to the current GPU and builds the nested-grid sample list. */
+int slamhip_create(const slamhip_desc* desc, slamhip_ctx** out);
+
+/* Replaces `lnprob`'s body (:597-602) for a whole batch: for each of the `nw`
+ * parameter rows computes cubemodel (:499-537, scaling='uniform') and
+ *   chi2 = nansum((data_valid - model)^2) / sigma^2 / pixperbeam.
+ * The caller applies -0.5 and the box prior (utils.py:32-36).
+ * `params` [nw][13] and `chi2_out` [nw] are host pointers. Synchronous. */
+int slamhip_chi2_batch(slamhip_ctx* ctx, const double* params, int nw,
+                       double* chi2_out);
+
+/* Same, with `params_dev` [nw][13] and `chi2_dev` [nw] already resident in
+ * device memory on the context's GPU.  Work is enqueued on `stream` (a
+ * hipStream_t passed as void*, NULL = default stream) and NOT waited for. */
+int slamhip_chi2_batch_dev(slamhip_ctx* ctx, const double* params_dev, int nw,
+                           double* chi2_dev, void* stream);
+
+/* Replaces `ChannelFit.cubemodel(*p, convolving)` (:499-537): writes the
+ * scaled model cube [nv][ny][nx] to the host buffer `out`.
+ * `stats_out` (may be NULL) receives {gf, ff, scale, chi2} (:485-490, :601). */
+int slamhip_cubemodel(slamhip_ctx* ctx, const double* params, int convolving,
+                      double* out, double* stats_out);
+
+/* Parity taps.  `get_Iunif` output (:454-473) [nv][nneed][nneed], and the
+ * beam-convolved cube (:530) on the same grid. */
+int slamhip_iunif(slamhip_ctx* ctx, const double* params, double* out);
+int slamhip_iconv(slamhip_ctx* ctx, const double* params, double* out);
+
+/* Per-surface geometry tap (:382-452): for surface slot s (0..3 = x1(h1),
+ * x2(h1), x1(h2), x2(h2)) writes xdisk and vlos (Mstar = 1) on the full nested
+ * grid [nlayer][npix][npix]; returns 1 if the slot is empty (None in the
+ * reference), 0 if written. */
+int slamhip_surface(slamhip_ctx* ctx, const double* params, int slot,
+                    double* xdisk_out, double* vlos_out);
+
+/* Line-profile table the kernels use for `cs` (:412-427): prof[45], prof_d. */
+int slamhip_prof(slamhip_ctx* ctx, double cs, double* prof_out,
+                 double* prof_d_out);
+
+/* Introspection: number of nested-grid samples that survive the layer merge,
+ * walkers processed per launch group, 1 if the beam was factorised exactly. */
+int slamhip_info(slamhip_ctx* ctx, int64_t* nleaf, int32_t* walkers_per_group,
+                 int32_t* separable_beam);
+
+/* Selects the convolution kernel: 0 = auto (separable when the beam is an
+ * outer product to 1e-14, else direct 2-D), 1 = force direct 2-D. */
+int slamhip_set_conv_mode(slamhip_ctx* ctx, int mode);
+
+const char* slamhip_last_error(slamhip_ctx* ctx);
+void slamhip_destroy(slamhip_ctx* ctx);
+
+/* Library-level: number of visible GPUs (0 if none), version string. */
+int slamhip_device_count(void);
+const char* slamhip_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SLAMHIP_H */

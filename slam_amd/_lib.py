@@ -1,0 +1,90 @@
+"""ctypes binding of libslamhip.so (declared in include/slamhip.h).
+
+There is no CPU fallback: if the shared library is missing or a call fails the
+caller gets an exception.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'libslamhip.so')
+
+NPARAM = 13
+PROF_LEN = 45
+
+_dp = C.POINTER(C.c_double)
+
+
+class SlamhipDesc(C.Structure):
+    """Mirror of `slamhip_desc` (include/slamhip.h)."""
+    _fields_ = [
+        ('nv', C.c_int32), ('ny', C.c_int32), ('nx', C.c_int32),
+        ('nlayer', C.c_int32), ('npix', C.c_int32),
+        ('nq1', C.c_int32), ('nq3', C.c_int32),
+        ('ineed0', C.c_int32), ('ineed1', C.c_int32),
+        ('kbeam', C.c_int32), ('disk', C.c_int32), ('envelope', C.c_int32),
+        ('dv', C.c_double), ('sigma', C.c_double), ('pixperbeam', C.c_double),
+        ('incl0', C.c_double), ('signmajor', C.c_double),
+        ('signminor', C.c_double), ('vunit', C.c_double),
+        ('Xnest0', _dp), ('Ynest0', _dp), ('xneed', _dp), ('yneed', _dp),
+        ('xobs', _dp), ('yobs', _dp), ('v_valid', _dp), ('data_valid', _dp),
+        ('gaussbeam', _dp),
+        ('max_scratch_bytes', C.c_int64),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/slamhip.h declares
+SYMBOLS = {
+    'slamhip_create': (C.c_int, [C.POINTER(SlamhipDesc), C.POINTER(C.c_void_p)]),
+    'slamhip_chi2_batch': (C.c_int, [C.c_void_p, _dp, C.c_int, _dp]),
+    'slamhip_chi2_batch_dev': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int,
+                                          C.c_void_p, C.c_void_p]),
+    'slamhip_cubemodel': (C.c_int, [C.c_void_p, _dp, C.c_int, _dp, _dp]),
+    'slamhip_iunif': (C.c_int, [C.c_void_p, _dp, _dp]),
+    'slamhip_iconv': (C.c_int, [C.c_void_p, _dp, _dp]),
+    'slamhip_surface': (C.c_int, [C.c_void_p, _dp, C.c_int, _dp, _dp]),
+    'slamhip_prof': (C.c_int, [C.c_void_p, C.c_double, _dp, _dp]),
+    'slamhip_info': (C.c_int, [C.c_void_p, C.POINTER(C.c_int64),
+                               C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    'slamhip_set_conv_mode': (C.c_int, [C.c_void_p, C.c_int]),
+    'slamhip_last_error': (C.c_char_p, [C.c_void_p]),
+    'slamhip_destroy': (None, [C.c_void_p]),
+    'slamhip_device_count': (C.c_int, []),
+    'slamhip_version': (C.c_char_p, []),
+}
+
+_lib = None
+
+
+class SlamhipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libslamhip.so (once) and declare every prototype."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SlamhipError(
+            f'{LIB_PATH} not found: build it with `python -m slam_amd.build` '
+            '(hipcc --offload-arch=gfx950). There is no CPU fallback.')
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def as_dp(a):
+    return a.ctypes.data_as(_dp)
+
+
+def f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)

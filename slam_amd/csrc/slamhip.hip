@@ -1,0 +1,1123 @@
+// slamhip.hip -- MI355X (gfx950) kernels + C ABI for SLAM channelfit's batched
+// likelihood: Keplerian-disk channel-map model + chi-square against the
+// observed cube, one launch group for many emcee walkers.
+//
+// Reference behaviour restated (jinshisai/SLAM, channelfit/_channelfit.py):
+//   update_pa :373-374   update_incl :376-380   update_xdisk :382-410
+//   update_prof :412-427 getvlos :429-449       get_Iunif :454-473
+//   convolve :530        rgi2d :475-483         get_scale :485-490
+//   chi2 :601-602
+// The design (sample list, kernels, HBM layout, rooflines) is in DESIGN.md.
+//
+// Pipeline per walker group (all fp64, HBM-resident intermediates):
+//   k_prep     : per-walker constants + 45-entry line-profile table
+//   k_surface  : deprojection + line-of-sight velocity per nested-grid sample
+//   k_profile  : line profile into velocity channels + nested-layer merge
+//   k_conv_sep / k_conv_2d : Gaussian beam convolution staged through LDS
+//   k_regrid   : bilinear regrid to observed pixels + fused sum(I*d), sum(I*I)
+//   k_finalize : fixed-order partial reduction -> scale, chi2
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+#include "slamhip.h"
+
+namespace {
+
+constexpr int NP = SLAMHIP_NPARAM;
+constexpr int PROF_LEN = SLAMHIP_PROF_LEN;   // 45
+constexpr int PROF_N = PROF_LEN - 1;         // 44 (:427)
+constexpr double VL_MASKED = 1.0e300;        // stands in for a NaN vlos
+constexpr double IDX_GUARD = 1.0e-9;         // |iv - integer| below this -> exact path
+constexpr int CH = 32;                       // channels accumulated in registers
+constexpr int CONV_TX = 64;                  // conv tile width (= one wave)
+constexpr int CONV_R = 8;                    // outputs per thread along the tap axis
+constexpr int RED_THREADS = 256;
+
+// ---------------------------------------------------------------------------
+// Device-resident constants of one fit (what makegrid leaves on `self`).
+// ---------------------------------------------------------------------------
+struct FitK {
+  int nv, ny, nx, nlayer, npix, nq1, nq3, ineed0, ineed1, nneed, kbeam, ngauss;
+  int disk, envelope;
+  int nvpad;            // nv rounded up to a multiple of CH
+  long long nleaf;      // nested-grid samples that survive the layer merge
+  double dv, sigma, pixperbeam, incl0, signmajor, signminor, vunit;
+  double ssq_data;      // sum(data_valid^2), fixed per fit
+  int data_has_nan;
+  const double* Xnest0;
+  const double* Ynest0;
+  const double* xneed;
+  const double* yneed;
+  const double* xobs;
+  const double* yobs;
+  const double* vpad;       // [nvpad] v_valid padded with +1e300
+  const double* ch_vmin;    // [nvpad/CH]
+  const double* ch_vmax;
+  const double* data;       // [nv][ny][nx]
+  const double* beam;       // [K][K]
+  const double* gx_pad;     // separable factors, flipped + zero padded
+  const double* gy_pad;
+  const unsigned* leaf;     // packed (layer:4 | row:14 | col:14)
+  const int* leaf_off;      // [nneed*nneed + 1] CSR offsets, pixel-major
+};
+
+// Per-walker constants written by k_prep.
+struct WalkerK {
+  double cp, sp;                 // cos/sin(radians(paoff))            :374
+  double sini, cosi, tani;       // :377-380
+  double sqrtM, Rc, Rin, pI, Ienv, voff, xoff, yoff;
+  double inv_ienv1;              // 1/(Ienv+1)
+  double prof_d, rinv;           // table step (:418), 1/(dv*prof_d)
+  double halfwidth;              // |v - vlos - voff| beyond this -> prof == 0
+  int nsurf;                     // live surfaces (<= 4)
+  int slot_surf[4];              // reference slot -> live surface (-1 = None)
+  int kind[4];                   // 1 thin, 2 one root, 3 root +, 4 root -
+  double h2[4];                  // h^2
+  double hfac[4];                // (1+h^2)^(-3/4)                    :435
+  double qa[4];                  // tan^-2 i - h^2                    :393
+  double qk[4];                  // tan^2 i - h^2                     :395
+  double wmul[4];                // 2 for the doubled thin surface    :389-390
+  double prof[PROF_LEN];
+};
+
+// ---------------------------------------------------------------------------
+// k_prep: one 64-thread block per walker.
+// ---------------------------------------------------------------------------
+__device__ inline double sgn(double x) { return (x > 0) - (x < 0); }
+
+__global__ void k_prep(FitK g, const double* __restrict__ params, int nw,
+                       WalkerK* __restrict__ wk) {
+  const int w = blockIdx.x;
+  if (w >= nw) return;
+  const double* p = params + (long long)w * NP;
+  WalkerK& o = wk[w];
+  const int t = threadIdx.x;
+  const double cs = p[2];
+  // update_prof (:412-427)
+  const double c = cs / g.dv;
+  const double wid = fmax(c * 2.35482, 1.0);
+  const double vmax = 2.0 * wid;
+  const double d = wid / 11.0;
+  if (t < PROF_LEN) {
+    const double step = (vmax - (-vmax)) / (double)PROF_N;
+    double u = (double)t * step + (-vmax);
+    if (t == PROF_N) u = vmax;
+    double val;
+    if (c < 0.01) {
+      val = (1.0 + sgn(u + 0.5)) * (1.0 - sgn(u - 0.5)) / 4.0;
+    } else {
+      const double s2 = sqrt(2.0);
+      val = erf((u + 0.5) / s2 / c) - erf((u - 0.5) / s2 / c);
+      if (t == 0 || t == PROF_N) val = 0.0;
+    }
+    o.prof[t] = val;
+  }
+  if (t == 0) {
+    const double Mstar = p[0], Rc = p[1], h1 = p[3], h2v = p[4], pI = p[5];
+    const double Rin = p[6], Ienv = p[7];
+    const double deg = M_PI / 180.0;
+    const double pa = p[12] * deg;
+    o.cp = cos(pa);
+    o.sp = sin(pa);
+    const double inc = (g.incl0 + p[11]) * deg;
+    o.sini = sin(inc);
+    o.cosi = cos(inc);
+    o.tani = tan(inc);
+    o.sqrtM = sqrt(Mstar);
+    o.Rc = Rc; o.Rin = Rin; o.pI = pI; o.Ienv = Ienv;
+    o.xoff = p[8]; o.yoff = p[9]; o.voff = p[10];
+    o.inv_ienv1 = 1.0 / (Ienv + 1.0);
+    o.prof_d = d;
+    o.rinv = 1.0 / (g.dv * d);
+    // prof[idx] != 0 only for idx in [1, 43]: |(v-vlos-voff) * rinv| < 22.5
+    o.halfwidth = 22.6 * fabs(g.dv * d);
+    int ns = 0;
+    const double hs[2] = {h1, h2v};
+    for (int k = 0; k < 2; ++k) {
+      const double h = hs[k];
+      int* slot = &o.slot_surf[2 * k];
+      slot[0] = slot[1] = -1;
+      if (h < 0) continue;                       // :385-387
+      const double hh = h * h;
+      const double hf = pow(1.0 + hh, -3.0 / 4.0);
+      const double a = pow(o.tani, -2.0) - hh;   // :393
+      const double kq = o.tani * o.tani - hh;    // :395
+      if (h < 0.01) {                            // :388-390, counted twice
+        o.kind[ns] = 1; o.h2[ns] = hh; o.hfac[ns] = hf; o.qa[ns] = a;
+        o.qk[ns] = kq; o.wmul[ns] = 2.0;
+        slot[0] = slot[1] = ns++;
+      } else if (-1e-3 < a && a < 1e-3) {        // :397-399
+        o.kind[ns] = 2; o.h2[ns] = hh; o.hfac[ns] = hf; o.qa[ns] = a;
+        o.qk[ns] = kq; o.wmul[ns] = 1.0;
+        slot[0] = ns++;
+      } else {                                   // :400-408
+        for (int r = 0; r < 2; ++r) {
+          o.kind[ns] = 3 + r; o.h2[ns] = hh; o.hfac[ns] = hf; o.qa[ns] = a;
+          o.qk[ns] = kq; o.wmul[ns] = 1.0;
+          slot[r] = ns++;
+        }
+      }
+    }
+    o.nsurf = ns;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Geometry of one sample on one surface: update_xdisk + getvlos.
+// ---------------------------------------------------------------------------
+struct Surf { double x, r, vlos; };
+
+__device__ inline Surf surface_eval(const FitK& g, const WalkerK& w, int s,
+                                    double X, double Y) {
+  const double nan = __builtin_nan("");
+  const int kind = w.kind[s];
+  const double hh = w.h2[s];
+  double x;
+  if (kind == 1) {
+    x = X / w.cosi;                                        // :389
+  } else {
+    const double Xc = X * w.cosi;                          // :392
+    const double b = (1.0 + hh) * Xc;                      // :394
+    const double c = w.qk[s] * (Xc * Xc) - hh * (Y * Y);   // :395-396
+    if (kind == 2) {
+      x = Xc + c / b / 2.0;                                // :398
+    } else {
+      const double a = w.qa[s];
+      const double D = b * b - a * c;                      // :403
+      if (D >= 0) {
+        const double rt = sqrt(D);
+        const double z = (kind == 3 ? (b + rt) : (b - rt)) / a;  // :405-406
+        x = Xc + z;
+      } else {
+        x = nan;
+      }
+    }
+  }
+  const double r = hypot(x, Y);                            // :433
+  const bool outer = r > w.Rc;                             // :434
+  const double rmh = 1.0 / sqrt(r);                        // r**(-1/2)
+  double vp = rmh * w.hfac[s];                             // :435
+  double vr = r * 0.0;                                     // :436
+  if (g.envelope && outer) {
+    vp = sqrt(w.Rc) / r;                                   // :438
+    vr = -rmh * sqrt(2.0 - w.Rc / r);                      // :439
+  }
+  const double erot = Y * g.signmajor / r;                 // :440
+  const double erad = x * g.signminor / r;                 // :441
+  double vlos = (vp * erot + vr * erad) * w.sini * g.vunit;  // :442
+  if (r < w.Rin) vlos = nan;                               // :443
+  if (!g.envelope && outer) vlos = nan;                    // :444-445
+  if (!g.disk && !outer) vlos = nan;                       // :446-447
+  Surf o;
+  o.x = x; o.r = r; o.vlos = vlos;
+  return o;
+}
+
+// k_surface: thread per (walker, surviving sample).  Writes, per live surface,
+//   vl = vlos*sqrt(Mstar)          (1e300 where the reference has NaN)
+//   wt = intensity weight * layer-merge weight 4^-layer
+// laid out [walker][surface][sample] so k_profile reads them coalesced.
+__global__ void __launch_bounds__(256)
+k_surface(FitK g, const WalkerK* __restrict__ wk, double* __restrict__ vl_out,
+          double* __restrict__ wt_out) {
+  const long long leaf = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (leaf >= g.nleaf) return;
+  const int wi = blockIdx.z;
+  const WalkerK& w = wk[wi];
+  const unsigned code = g.leaf[leaf];
+  const int l = code >> 28, j = (code >> 14) & 0x3fff, i = code & 0x3fff;
+  const long long idx = ((long long)l * g.npix + j) * g.npix + i;
+  const double X0 = g.Xnest0[idx], Y0 = g.Ynest0[idx];
+  const double X = X0 * w.cp - Y0 * w.sp;                  // utils.py:355
+  const double Y = X0 * w.sp + Y0 * w.cp;                  // utils.py:356
+  const double lw = 1.0 / (double)(1 << (2 * l));          // avefour nesting :469-471
+  for (int s = 0; s < w.nsurf; ++s) {
+    const Surf f = surface_eval(g, w, s, X, Y);
+    double vl = f.vlos * w.sqrtM;                          // :460
+    double wt = (f.r < w.Rc ? 1.0 : w.Ienv) * w.inv_ienv1; // :465
+    if (w.pI != 0.0) wt = wt * pow(f.r, -w.pI);            // :466-467
+    wt = wt * (lw * w.wmul[s]);
+    if (!(vl == vl) || !(wt == wt)) {                      // NaN -> contributes 0 (:463,:468)
+      vl = VL_MASKED;
+      wt = 0.0;
+    } else {
+      if (fabs(vl) > VL_MASKED) vl = VL_MASKED;
+      if (fabs(wt) > 1.79769313486231570815e308)           // nan_to_num(inf) :468
+        wt = copysign(1.79769313486231570815e308, wt);
+    }
+    const long long o = ((long long)wi * 4 + s) * g.nleaf + leaf;
+    vl_out[o] = vl;
+    wt_out[o] = wt;
+  }
+}
+
+// Tap for parity tests: xdisk / vlos(Mstar=1) on the full nested grid.
+__global__ void k_surface_tap(FitK g, const WalkerK* __restrict__ wk, int s,
+                              double* __restrict__ x_out,
+                              double* __restrict__ v_out) {
+  const long long n = (long long)g.nlayer * g.npix * g.npix;
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n) return;
+  const WalkerK& w = wk[0];
+  const double X0 = g.Xnest0[idx], Y0 = g.Ynest0[idx];
+  const double X = X0 * w.cp - Y0 * w.sp;
+  const double Y = X0 * w.sp + Y0 * w.cp;
+  const Surf f = surface_eval(g, w, s, X, Y);
+  x_out[idx] = f.x;
+  v_out[idx] = f.vlos;
+}
+
+// ---------------------------------------------------------------------------
+// k_profile: thread per output pixel of the cropped layer-0 grid.  For each
+// block of CH channels the thread walks its samples x surfaces, looks the
+// line profile up with the reference's truncating index (:462-463) and
+// accumulates in registers; then stores Iunif[k][j][i] (coalesced along i).
+// ---------------------------------------------------------------------------
+__device__ inline int prof_index(double vk, double vl, double o, double rinv,
+                                 const FitK& g, const WalkerK& w) {
+  // fast form (o = vl + voff): differs from the reference's iv by < 1e-12
+  const double t = fma(vk - o, rinv, 22.5);
+  int idx = (int)t;                       // saturating; NaN -> 0
+  if (fabs(t - rint(t)) < IDX_GUARD && t > 0.5 && t < 45.5) {
+    // too close to a table boundary: redo in the reference's exact order
+    //   iv = ((v_valid - vlos) - voff) / dv / prof_d + prof_n//2 + 0.5   (:461-462)
+    double v = vk - vl;
+    v = v - w.voff;
+    const double iv = v / g.dv / w.prof_d + 22.0 + 0.5;
+    idx = (int)iv;
+  }
+  return min(max(idx, 0), PROF_N);
+}
+
+__global__ void __launch_bounds__(256)
+k_profile(FitK g, const WalkerK* __restrict__ wk,
+          const double* __restrict__ vl_in, const double* __restrict__ wt_in,
+          double* __restrict__ iunif) {
+  __shared__ double s_prof[PROF_LEN];
+  const int wi = blockIdx.z;
+  const WalkerK& w = wk[wi];
+  if (threadIdx.x < PROF_LEN) s_prof[threadIdx.x] = w.prof[threadIdx.x];
+  __syncthreads();
+  const int npx = g.nneed * g.nneed;
+  const int pix = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pix >= npx) return;
+  const int l0 = g.leaf_off[pix], l1 = g.leaf_off[pix + 1];
+  const int nsurf = w.nsurf;
+  const double rinv = w.rinv, hw = w.halfwidth, voff = w.voff;
+  const double* vlw = vl_in + (long long)wi * 4 * g.nleaf;
+  const double* wtw = wt_in + (long long)wi * 4 * g.nleaf;
+  double* out = iunif + (long long)wi * g.nv * npx + pix;
+  const int nchunk = g.nvpad / CH;
+  for (int cix = 0; cix < nchunk; ++cix) {
+    double acc[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) acc[c] = 0.0;
+    const double cmin = g.ch_vmin[cix], cmax = g.ch_vmax[cix];
+    const double* vk = g.vpad + cix * CH;
+    for (int s = 0; s < nsurf; ++s) {
+      for (int lf = l0; lf < l1; ++lf) {
+        const double vl = vlw[(long long)s * g.nleaf + lf];
+        const double o = vl + voff;
+        if (cmin - o > hw || o - cmax > hw) continue;     // no channel of this block is lit
+        const double wt = wtw[(long long)s * g.nleaf + lf];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+          const int idx = prof_index(vk[c], vl, o, rinv, g, w);
+          acc[c] = fma(s_prof[idx], wt, acc[c]);
+        }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const int k = cix * CH + c;
+      if (k < g.nv) out[(long long)k * npx] = acc[c];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Beam convolution (:530): zero-padded 'same' convolution per channel.
+//
+// k_conv_sep: separable beam, row pass then column pass on one LDS tile.
+// The row-pass results are held in registers across the barrier so the same
+// LDS buffer serves as input tile and as the intermediate.  Each thread slides
+// a CONV_R-wide register window along the tap axis: 1 LDS read per CONV_R FMAs.
+// ---------------------------------------------------------------------------
+template <int TY, int MAXR>
+__global__ void __launch_bounds__(256)
+k_conv_sep(FitK g, const double* __restrict__ in, double* __restrict__ out,
+           int kpad) {
+  extern __shared__ double lds[];
+  constexpr int TX = CONV_TX, R = CONV_R;
+  const int K = g.kbeam, ng = g.ngauss, n = g.nneed;
+  const int rows = TY + kpad - 1;              // tile rows incl. halo + zero pad
+  const int cols = TX + kpad - 1;
+  const int P = cols | 1;                      // odd pitch: lanes<->rows conflict-free
+  const int P2 = TX + 1;
+  const int tid = threadIdx.x;
+  const long long plane = (long long)n * n;
+  const double* src = in + (long long)blockIdx.z * plane;
+  double* dst = out + (long long)blockIdx.z * plane;
+  const int x0 = blockIdx.x * TX, y0 = blockIdx.y * TY;
+
+  // 1. stage the input tile (zero outside the image and in the pad)
+  for (int e = tid; e < rows * P; e += 256) {
+    const int rr = e / P, cc = e - rr * P;
+    const int gy = y0 - ng + rr, gx = x0 - ng + cc;
+    double v = 0.0;
+    if (rr < TY + K - 1 && cc < TX + K - 1 && gy >= 0 && gy < n && gx >= 0 && gx < n)
+      v = src[(long long)gy * n + gx];
+    lds[e] = v;
+  }
+  __syncthreads();
+
+  // 2. row pass: tmp[row][x] = sum_u gxf[u] * tile[row][x+u]
+  const int nitem = rows * (TX / R);
+  double res[MAXR][R];
+  const double* wx = g.gx_pad;                 // flipped taps, zero padded to kpad
+#pragma unroll
+  for (int q = 0; q < MAXR; ++q) {
+    const int item = q * 256 + tid;
+#pragma unroll
+    for (int r = 0; r < R; ++r) res[q][r] = 0.0;
+    if (item < nitem) {
+      const int xb = item / rows, rr = item - xb * rows;
+      const double* row = lds + rr * P + xb * R;
+      double win[R];
+#pragma unroll
+      for (int r = 0; r < R - 1; ++r) win[r] = row[r];
+      for (int u0 = 0; u0 < kpad; u0 += R) {
+#pragma unroll
+        for (int qq = 0; qq < R; ++qq) {
+          win[(qq + R - 1) % R] = row[u0 + qq + R - 1];
+          const double wgt = wx[u0 + qq];
+#pragma unroll
+          for (int r = 0; r < R; ++r)
+            res[q][r] = fma(wgt, win[(r + qq) % R], res[q][r]);
+        }
+      }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < MAXR; ++q) {
+    const int item = q * 256 + tid;
+    if (item < nitem) {
+      const int xb = item / rows, rr = item - xb * rows;
+#pragma unroll
+      for (int r = 0; r < R; ++r) lds[rr * P2 + xb * R + r] = res[q][r];
+    }
+  }
+  __syncthreads();
+
+  // 3. column pass: out[y][x] = sum_u gyf[u] * tmp[y+u][x]; lanes <-> x
+  const double* wy = g.gy_pad;
+  const int lane_x = tid & (TX - 1);
+  for (int yb = tid / TX; yb < TY / R; yb += 256 / TX) {
+    const double* col = lds + (yb * R) * P2 + lane_x;
+    double acc[R], win[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = 0.0;
+#pragma unroll
+    for (int r = 0; r < R - 1; ++r) win[r] = col[r * P2];
+    for (int u0 = 0; u0 < kpad; u0 += R) {
+#pragma unroll
+      for (int qq = 0; qq < R; ++qq) {
+        win[(qq + R - 1) % R] = col[(u0 + qq + R - 1) * P2];
+        const double wgt = wy[u0 + qq];
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+          acc[r] = fma(wgt, win[(r + qq) % R], acc[r]);
+      }
+    }
+    const int gx = x0 + lane_x;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int gy = y0 + yb * R + r;
+      if (gx < n && gy < n) dst[(long long)gy * n + gx] = acc[r];
+    }
+  }
+}
+
+// k_conv_2d: general (rotated) beam, direct K x K taps on an LDS tile.
+constexpr int C2_TX = 64, C2_TY = 16, C2_RY = 4;
+__global__ void __launch_bounds__(256)
+k_conv_2d(FitK g, const double* __restrict__ in, double* __restrict__ out) {
+  extern __shared__ double lds[];
+  const int K = g.kbeam, ng = g.ngauss, n = g.nneed;
+  const int rows = C2_TY + K - 1, cols = C2_TX + K - 1;
+  const int P = cols | 1;
+  const int tid = threadIdx.x;
+  const long long plane = (long long)n * n;
+  const double* src = in + (long long)blockIdx.z * plane;
+  double* dst = out + (long long)blockIdx.z * plane;
+  const int x0 = blockIdx.x * C2_TX, y0 = blockIdx.y * C2_TY;
+  for (int e = tid; e < rows * P; e += 256) {
+    const int rr = e / P, cc = e - rr * P;
+    const int gy = y0 - ng + rr, gx = x0 - ng + cc;
+    double v = 0.0;
+    if (cc < cols && gy >= 0 && gy < n && gx >= 0 && gx < n)
+      v = src[(long long)gy * n + gx];
+    lds[e] = v;
+  }
+  __syncthreads();
+  const int tx = tid & 63, ty = tid >> 6;          // 4 row groups
+  double acc[C2_RY];
+#pragma unroll
+  for (int r = 0; r < C2_RY; ++r) acc[r] = 0.0;
+  // out[y][x] = sum_{dy,dx} beam[dy][dx] * in[y+ng-dy][x+ng-dx]
+  //           = sum_{a,b} beam[K-1-a][K-1-b] * tile[y+a][x+b]
+  for (int a = 0; a < K; ++a) {
+    const double* brow = g.beam + (long long)(K - 1 - a) * K;
+    for (int b = 0; b < K; ++b) {
+      const double wgt = brow[K - 1 - b];
+#pragma unroll
+      for (int r = 0; r < C2_RY; ++r)
+        acc[r] = fma(wgt, lds[(ty + 4 * r + a) * P + tx + b], acc[r]);
+    }
+  }
+  const int gx = x0 + tx;
+#pragma unroll
+  for (int r = 0; r < C2_RY; ++r) {
+    const int gy = y0 + ty + 4 * r;
+    if (gx < n && gy < n) dst[(long long)gy * n + gx] = acc[r];
+  }
+}
+
+// peaktounity (:492-497): per-channel max, then scale by 1/max (0 if max == 0).
+__global__ void __launch_bounds__(256)
+k_peak_unity(FitK g, const double* __restrict__ in, double* __restrict__ out) {
+  __shared__ double red[256];
+  const long long plane = (long long)g.nneed * g.nneed;
+  const double* src = in + (long long)blockIdx.x * plane;
+  double* dst = out + (long long)blockIdx.x * plane;
+  double m = -std::numeric_limits<double>::infinity();
+  for (long long e = threadIdx.x; e < plane; e += 256) m = fmax(m, src[e]);
+  red[threadIdx.x] = m;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + s]);
+    __syncthreads();
+  }
+  const double peak = red[0];
+  const double sc = (peak == 0.0) ? 0.0 : 1.0 / peak;
+  for (long long e = threadIdx.x; e < plane; e += 256) dst[e] = src[e] * sc;
+}
+
+// ---------------------------------------------------------------------------
+// k_regrid: bilinear regrid onto the observed pixels (:475-483, scipy
+// RegularGridInterpolator linear, fill 0 outside) fused with the two sums of
+// get_scale (:485-490).  Wave shuffle reduction, then a block reduction; the
+// per-block partials are summed in fixed order by k_finalize.
+// ---------------------------------------------------------------------------
+__device__ inline int find_cell(const double* __restrict__ gr, int n, double q,
+                                double inv_step) {
+  // i with gr[i] <= q < gr[i+1], clipped to [0, n-2] (searchsorted semantics)
+  int i = (int)floor((q - gr[0]) * inv_step);
+  i = min(max(i, 0), n - 2);
+  while (i > 0 && q < gr[i]) --i;
+  while (i < n - 2 && q >= gr[i + 1]) ++i;
+  return i;
+}
+
+__device__ inline double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+template <bool WRITE>
+__global__ void __launch_bounds__(RED_THREADS)
+k_regrid(FitK g, const WalkerK* __restrict__ wk, const double* __restrict__ iconv,
+         double* __restrict__ partial, double* __restrict__ cube_out) {
+  const int wi = blockIdx.z;
+  const WalkerK& w = wk[wi];
+  const int n = g.nneed;
+  const long long nobs = (long long)g.ny * g.nx;
+  const long long total = nobs * g.nv;
+  const double* src = iconv + (long long)wi * g.nv * n * n;
+  const double inv_sx = 1.0 / (g.xneed[1] - g.xneed[0]);
+  const double inv_sy = 1.0 / (g.yneed[1] - g.yneed[0]);
+  double gf = 0.0, ff = 0.0;
+  for (long long e = (long long)blockIdx.x * RED_THREADS + threadIdx.x; e < total;
+       e += (long long)gridDim.x * RED_THREADS) {
+    const int k = (int)(e / nobs);
+    const int rem = (int)(e - (long long)k * nobs);
+    const int jy = rem / g.nx, ix = rem - jy * g.nx;
+    const double qx = g.xobs[ix] - w.xoff;                 // :481
+    const double qy = g.yobs[jy] - w.yoff;
+    double val;
+    if (qx != qx || qy != qy) {
+      val = __builtin_nan("");
+    } else if (qx < g.xneed[0] || qx > g.xneed[n - 1] || qy < g.yneed[0] ||
+               qy > g.yneed[n - 1]) {
+      val = 0.0;                                           // fill_value=0
+    } else {
+      const int i1 = find_cell(g.xneed, n, qx, inv_sx);
+      const int i0 = find_cell(g.yneed, n, qy, inv_sy);
+      const double t1 = (qx - g.xneed[i1]) / (g.xneed[i1 + 1] - g.xneed[i1]);
+      const double t0 = (qy - g.yneed[i0]) / (g.yneed[i0 + 1] - g.yneed[i0]);
+      const double* c = src + ((long long)k * n + i0) * n + i1;
+      const double v00 = c[0], v01 = c[1], v10 = c[n], v11 = c[n + 1];
+      val = v00 * (1 - t0) * (1 - t1) + v01 * (1 - t0) * t1 +
+            v10 * t0 * (1 - t1) + v11 * t0 * t1;
+    }
+    if (WRITE) cube_out[e] = val;
+    gf = fma(val, g.data[e], gf);
+    ff = fma(val, val, ff);
+  }
+  __shared__ double sg[RED_THREADS / 64], sf[RED_THREADS / 64];
+  gf = wave_sum(gf);
+  ff = wave_sum(ff);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0) { sg[wv] = gf; sf[wv] = ff; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double a = 0.0, b = 0.0;
+    for (int q = 0; q < RED_THREADS / 64; ++q) { a += sg[q]; b += sf[q]; }
+    double* p = partial + ((long long)wi * gridDim.x + blockIdx.x) * 2;
+    p[0] = a;
+    p[1] = b;
+  }
+}
+
+// k_finalize: one block per walker; fixed-order sum of the partials, then
+//   scale = gf/ff, 0 if ff == 0 or scale < 0                        (:488-489)
+//   chi2  = sum((d - scale*I)^2)/sigma^2/pixperbeam                 (:601-602)
+//         = (sum d^2 - 2 s gf + s^2 ff)/sigma^2/pixperbeam
+// stats[w] = {gf, ff, scale, chi2}
+__global__ void __launch_bounds__(64)
+k_finalize(FitK g, const double* __restrict__ partial, int nblk,
+           double* __restrict__ stats, double* __restrict__ chi2_out) {
+  const int wi = blockIdx.x;
+  const double* p = partial + (long long)wi * nblk * 2;
+  double a = 0.0, b = 0.0;
+  for (int q = threadIdx.x; q < nblk; q += 64) { a += p[2 * q]; b += p[2 * q + 1]; }
+  a = wave_sum(a);
+  b = wave_sum(b);
+  if (threadIdx.x == 0) {
+    double s = a / b;
+    if (b == 0.0 || s < 0.0) s = 0.0;
+    double c2;
+    if (g.data_has_nan || a != a || b != b) {
+      // np.sum propagates the NaN into the scale, the whole model becomes NaN
+      // and nansum() of an all-NaN residual is 0 (:486-489, :601).
+      c2 = 0.0;
+    } else {
+      c2 = (g.ssq_data - 2.0 * s * a + s * s * b) / (g.sigma * g.sigma) / g.pixperbeam;
+    }
+    if (stats) {
+      stats[4 * wi + 0] = a; stats[4 * wi + 1] = b;
+      stats[4 * wi + 2] = s; stats[4 * wi + 3] = c2;
+    }
+    if (chi2_out) chi2_out[wi] = c2;
+  }
+}
+
+__global__ void k_scale(double* __restrict__ cube, long long n,
+                        const double* __restrict__ stats) {
+  const double s = stats[2];
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n;
+       e += (long long)gridDim.x * blockDim.x)
+    cube[e] = cube[e] * s;
+}
+
+}  // namespace
+
+// ===========================================================================
+// Host side
+// ===========================================================================
+struct slamhip_ctx {
+  int device = 0;
+  FitK k{};
+  std::string err;
+  std::vector<void*> allocs;
+  // per-group scratch
+  int wgroup = 0;          // walkers per launch group
+  WalkerK* d_wk = nullptr;
+  double* d_params = nullptr;
+  double* d_vl = nullptr;
+  double* d_wt = nullptr;
+  double* d_iunif = nullptr;
+  double* d_iconv = nullptr;
+  double* d_partial = nullptr;
+  double* d_stats = nullptr;
+  double* d_chi2 = nullptr;
+  int red_blocks = 0;
+  int separable = 0;
+  int conv_mode = 0;
+  int kpad = 0;
+  int sep_variant = 0;     // 0: <64,3>  1: <64,5>  2: <32,4>  -1: none fits
+  size_t sep_lds = 0, c2d_lds = 0;
+  hipStream_t stream = nullptr;
+};
+
+namespace {
+
+int fail(slamhip_ctx* c, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (c) c->err = buf;
+  return code;
+}
+
+#define HIP_TRY(c, expr)                                                       \
+  do {                                                                         \
+    hipError_t e_ = (expr);                                                    \
+    if (e_ != hipSuccess)                                                      \
+      return fail((c), e_ == hipErrorOutOfMemory ? SLAMHIP_ERR_NOMEM           \
+                                                 : SLAMHIP_ERR_HIP,            \
+                  "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),       \
+                  __FILE__, __LINE__);                                         \
+  } while (0)
+
+template <typename T>
+int dev_alloc(slamhip_ctx* c, T** p, size_t count) {
+  void* q = nullptr;
+  HIP_TRY(c, hipMalloc(&q, std::max<size_t>(count, 1) * sizeof(T)));
+  c->allocs.push_back(q);
+  *p = static_cast<T*>(q);
+  return SLAMHIP_OK;
+}
+
+template <typename T>
+int dev_upload(slamhip_ctx* c, const T** p, const T* host, size_t count) {
+  T* q = nullptr;
+  int rc = dev_alloc(c, &q, count);
+  if (rc) return rc;
+  HIP_TRY(c, hipMemcpy(q, host, count * sizeof(T), hipMemcpyHostToDevice));
+  *p = q;
+  return SLAMHIP_OK;
+}
+
+// Samples that survive the layer merge (:469-472), listed per output pixel.
+// A pixel of layer l inside the inner quadrant [nq1,nq3)^2 is replaced by the
+// mean of its 2x2 children in layer l+1 (recursively), in avefour's order.
+void collect_leaves(const slamhip_desc& d, int l, int j, int i,
+                    std::vector<unsigned>& out) {
+  const bool inner = j >= d.nq1 && j < d.nq3 && i >= d.nq1 && i < d.nq3;
+  if (l + 1 < d.nlayer && inner) {
+    for (int a = 0; a < 2; ++a)
+      for (int b = 0; b < 2; ++b)
+        collect_leaves(d, l + 1, 2 * (j - d.nq1) + a, 2 * (i - d.nq1) + b, out);
+  } else {
+    out.push_back(((unsigned)l << 28) | ((unsigned)j << 14) | (unsigned)i);
+  }
+}
+
+int check_desc(const slamhip_desc* d) {
+  if (!d) return 1;
+  if (d->nv < 1 || d->ny < 1 || d->nx < 1) return 2;
+  if (d->nlayer < 1 || d->nlayer > 8) return 3;
+  if (d->npix < 4 || d->npix > 16383) return 4;
+  if (d->nq1 < 0 || d->nq3 > d->npix || d->nq3 - d->nq1 != d->npix / 2) return 5;
+  if (d->ineed0 < 0 || d->ineed1 > d->npix || d->ineed1 - d->ineed0 < 2) return 6;
+  if (d->kbeam < 1 || d->kbeam % 2 == 0) return 7;
+  if (!d->Xnest0 || !d->Ynest0 || !d->xneed || !d->yneed || !d->xobs ||
+      !d->yobs || !d->v_valid || !d->data_valid || !d->gaussbeam)
+    return 8;
+  if (!(d->dv != 0.0) || !(d->sigma > 0.0) || !(d->pixperbeam > 0.0)) return 9;
+  // every child index 2*(j-nq1)+a must stay inside the next layer
+  if (2 * (d->nq3 - 1 - d->nq1) + 1 >= d->npix) return 10;
+  return 0;
+}
+
+template <int TY, int MAXR>
+void launch_conv_sep(slamhip_ctx* c, const double* in, double* out, int planes,
+                     hipStream_t st) {
+  const int n = c->k.nneed;
+  dim3 grid((n + CONV_TX - 1) / CONV_TX, (n + TY - 1) / TY, planes);
+  hipLaunchKernelGGL((k_conv_sep<TY, MAXR>), grid, dim3(256), c->sep_lds, st,
+                     c->k, in, out, c->kpad);
+}
+
+size_t sep_lds_bytes(int TY, int kpad) {
+  const int rows = TY + kpad - 1;
+  const int P = (CONV_TX + kpad - 1) | 1;
+  return (size_t)rows * std::max(P, CONV_TX + 1) * sizeof(double);
+}
+
+int run_conv(slamhip_ctx* c, const double* in, double* out, int planes,
+             hipStream_t st) {
+  const int n = c->k.nneed;
+  const bool sep = c->separable && c->conv_mode == 0 && c->sep_variant >= 0;
+  // grid.z is limited to 65535 planes per launch
+  for (int p0 = 0; p0 < planes; p0 += 32768) {
+    const int np_ = std::min(32768, planes - p0);
+    const double* src = in + (long long)p0 * n * n;
+    double* dst = out + (long long)p0 * n * n;
+    if (sep) {
+      switch (c->sep_variant) {
+        case 0: launch_conv_sep<64, 3>(c, src, dst, np_, st); break;
+        case 1: launch_conv_sep<64, 5>(c, src, dst, np_, st); break;
+        default: launch_conv_sep<32, 4>(c, src, dst, np_, st); break;
+      }
+    } else {
+      if (c->c2d_lds > 160 * 1024)
+        return fail(c, SLAMHIP_ERR_ARG, "beam kernel %d too large for the 2-D LDS tile",
+                    c->k.kbeam);
+      dim3 grid((n + C2_TX - 1) / C2_TX, (n + C2_TY - 1) / C2_TY, np_);
+      hipLaunchKernelGGL(k_conv_2d, grid, dim3(256), c->c2d_lds, st, c->k, src, dst);
+    }
+  }
+  HIP_TRY(c, hipGetLastError());
+  return SLAMHIP_OK;
+}
+
+// Stages shared by every entry point: params (device) -> iunif for `nw` walkers
+int run_model(slamhip_ctx* c, const double* d_params, int nw, hipStream_t st) {
+  const FitK& k = c->k;
+  hipLaunchKernelGGL(k_prep, dim3(nw), dim3(64), 0, st, k, d_params, nw, c->d_wk);
+  dim3 g1((unsigned)((k.nleaf + 255) / 256), 1, nw);
+  hipLaunchKernelGGL(k_surface, g1, dim3(256), 0, st, k, c->d_wk, c->d_vl, c->d_wt);
+  dim3 g2((k.nneed * k.nneed + 255) / 256, 1, nw);
+  hipLaunchKernelGGL(k_profile, g2, dim3(256), 0, st, k, c->d_wk, c->d_vl, c->d_wt,
+                     c->d_iunif);
+  HIP_TRY(c, hipGetLastError());
+  return SLAMHIP_OK;
+}
+
+int run_group(slamhip_ctx* c, const double* d_params, int nw, double* d_chi2,
+              hipStream_t st) {
+  int rc = run_model(c, d_params, nw, st);
+  if (rc) return rc;
+  rc = run_conv(c, c->d_iunif, c->d_iconv, nw * c->k.nv, st);
+  if (rc) return rc;
+  dim3 g4(c->red_blocks, 1, nw);
+  hipLaunchKernelGGL((k_regrid<false>), g4, dim3(RED_THREADS), 0, st, c->k, c->d_wk,
+                     c->d_iconv, c->d_partial, (double*)nullptr);
+  hipLaunchKernelGGL(k_finalize, dim3(nw), dim3(64), 0, st, c->k, c->d_partial,
+                     c->red_blocks, c->d_stats, d_chi2);
+  HIP_TRY(c, hipGetLastError());
+  return SLAMHIP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int slamhip_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+const char* slamhip_version(void) { return "slamhip 0.1 (gfx950, fp64)"; }
+
+const char* slamhip_last_error(slamhip_ctx* ctx) {
+  return ctx ? ctx->err.c_str() : "null context";
+}
+
+int slamhip_create(const slamhip_desc* d, slamhip_ctx** out) {
+  if (!out) return SLAMHIP_ERR_ARG;
+  *out = nullptr;
+  slamhip_ctx* c = new slamhip_ctx();
+  *out = c;   // returned even on failure so the caller can read the error
+  if (int bad = check_desc(d))
+    return fail(c, SLAMHIP_ERR_ARG, "invalid descriptor (check %d)", bad);
+  HIP_TRY(c, hipGetDevice(&c->device));
+  FitK& k = c->k;
+  k.nv = d->nv; k.ny = d->ny; k.nx = d->nx; k.nlayer = d->nlayer; k.npix = d->npix;
+  k.nq1 = d->nq1; k.nq3 = d->nq3; k.ineed0 = d->ineed0; k.ineed1 = d->ineed1;
+  k.nneed = d->ineed1 - d->ineed0; k.kbeam = d->kbeam; k.ngauss = (d->kbeam - 1) / 2;
+  k.disk = d->disk != 0; k.envelope = d->envelope != 0;
+  k.dv = d->dv; k.sigma = d->sigma; k.pixperbeam = d->pixperbeam; k.incl0 = d->incl0;
+  k.signmajor = d->signmajor; k.signminor = d->signminor; k.vunit = d->vunit;
+  k.nvpad = (k.nv + CH - 1) / CH * CH;
+  const int n = k.nneed, K = k.kbeam;
+  const size_t ngrid = (size_t)k.nlayer * k.npix * k.npix;
+  const size_t ncube = (size_t)k.nv * k.ny * k.nx;
+
+  // --- sample list ---------------------------------------------------------
+  std::vector<unsigned> leaves;
+  std::vector<int> off((size_t)n * n + 1);
+  leaves.reserve((size_t)n * n * 3);
+  for (int j = 0; j < n; ++j)
+    for (int i = 0; i < n; ++i) {
+      off[(size_t)j * n + i] = (int)leaves.size();
+      collect_leaves(*d, 0, j + k.ineed0, i + k.ineed0, leaves);
+    }
+  off[(size_t)n * n] = (int)leaves.size();
+  k.nleaf = (long long)leaves.size();
+
+  // --- data statistics -------------------------------------------------------
+  {
+    double s = 0.0, comp = 0.0;   // Kahan
+    int has_nan = 0;
+    for (size_t e = 0; e < ncube; ++e) {
+      const double v = d->data_valid[e];
+      if (v != v) { has_nan = 1; continue; }
+      const double y = v * v - comp, t = s + y;
+      comp = (t - s) - y;
+      s = t;
+    }
+    k.ssq_data = s;
+    k.data_has_nan = has_nan;
+  }
+
+  // --- channel table padded to CH, with per-block velocity range -----------
+  std::vector<double> vpad(k.nvpad, 1.0e300), cmin(k.nvpad / CH), cmax(k.nvpad / CH);
+  for (int q = 0; q < k.nv; ++q) vpad[q] = d->v_valid[q];
+  for (int b = 0; b < k.nvpad / CH; ++b) {
+    double lo = std::numeric_limits<double>::infinity(), hi = -lo;
+    for (int q = b * CH; q < std::min(k.nv, (b + 1) * CH); ++q) {
+      lo = std::min(lo, vpad[q]);
+      hi = std::max(hi, vpad[q]);
+    }
+    cmin[b] = lo; cmax[b] = hi;
+  }
+
+  // --- beam: separable when it is an outer product of its central row/col --
+  const int cc = k.ngauss;
+  const double peak = d->gaussbeam[(size_t)cc * K + cc];
+  double worst = 0.0;
+  for (int y = 0; y < K && peak != 0.0; ++y)
+    for (int x = 0; x < K; ++x) {
+      const double sepv = d->gaussbeam[(size_t)y * K + cc] * d->gaussbeam[(size_t)cc * K + x] / peak;
+      worst = std::max(worst, std::fabs(sepv - d->gaussbeam[(size_t)y * K + x]));
+    }
+  c->separable = (peak != 0.0 && worst <= 1e-14 * std::fabs(peak)) ? 1 : 0;
+  c->kpad = (K + CONV_R - 1) / CONV_R * CONV_R;
+  std::vector<double> gx(c->kpad, 0.0), gy(c->kpad, 0.0);
+  if (c->separable)
+    for (int u = 0; u < K; ++u) {   // flipped: correlation taps
+      gx[u] = d->gaussbeam[(size_t)cc * K + (K - 1 - u)];
+      gy[u] = d->gaussbeam[(size_t)(K - 1 - u) * K + cc] / peak;
+    }
+  c->sep_variant = -1;
+  if (sep_lds_bytes(64, c->kpad) <= 80 * 1024 && (64 + c->kpad - 1) * (CONV_TX / CONV_R) <= 3 * 256) {
+    c->sep_variant = 0; c->sep_lds = sep_lds_bytes(64, c->kpad);
+  } else if (sep_lds_bytes(64, c->kpad) <= 160 * 1024 && (64 + c->kpad - 1) * (CONV_TX / CONV_R) <= 5 * 256) {
+    c->sep_variant = 1; c->sep_lds = sep_lds_bytes(64, c->kpad);
+  } else if (sep_lds_bytes(32, c->kpad) <= 160 * 1024 && (32 + c->kpad - 1) * (CONV_TX / CONV_R) <= 4 * 256) {
+    c->sep_variant = 2; c->sep_lds = sep_lds_bytes(32, c->kpad);
+  }
+  c->c2d_lds = (size_t)(C2_TY + K - 1) * ((C2_TX + K - 1) | 1) * sizeof(double);
+  if (c->sep_lds > 64 * 1024) {
+    HIP_TRY(c, hipFuncSetAttribute((const void*)k_conv_sep<64, 5>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIP_TRY(c, hipFuncSetAttribute((const void*)k_conv_sep<64, 3>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIP_TRY(c, hipFuncSetAttribute((const void*)k_conv_sep<32, 4>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  }
+  if (c->c2d_lds > 64 * 1024)
+    HIP_TRY(c, hipFuncSetAttribute((const void*)k_conv_2d,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+
+  // --- uploads -------------------------------------------------------------
+  int rc;
+  if ((rc = dev_upload(c, &k.Xnest0, d->Xnest0, ngrid))) return rc;
+  if ((rc = dev_upload(c, &k.Ynest0, d->Ynest0, ngrid))) return rc;
+  if ((rc = dev_upload(c, &k.xneed, d->xneed, (size_t)n))) return rc;
+  if ((rc = dev_upload(c, &k.yneed, d->yneed, (size_t)n))) return rc;
+  if ((rc = dev_upload(c, &k.xobs, d->xobs, (size_t)k.nx))) return rc;
+  if ((rc = dev_upload(c, &k.yobs, d->yobs, (size_t)k.ny))) return rc;
+  if ((rc = dev_upload(c, &k.vpad, vpad.data(), vpad.size()))) return rc;
+  if ((rc = dev_upload(c, &k.ch_vmin, cmin.data(), cmin.size()))) return rc;
+  if ((rc = dev_upload(c, &k.ch_vmax, cmax.data(), cmax.size()))) return rc;
+  if ((rc = dev_upload(c, &k.data, d->data_valid, ncube))) return rc;
+  if ((rc = dev_upload(c, &k.beam, d->gaussbeam, (size_t)K * K))) return rc;
+  if ((rc = dev_upload(c, &k.gx_pad, gx.data(), gx.size()))) return rc;
+  if ((rc = dev_upload(c, &k.gy_pad, gy.data(), gy.size()))) return rc;
+  if ((rc = dev_upload(c, &k.leaf, leaves.data(), leaves.size()))) return rc;
+  if ((rc = dev_upload(c, &k.leaf_off, off.data(), off.size()))) return rc;
+
+  // --- per-group scratch -----------------------------------------------------
+  const size_t per_walker = sizeof(double) * (8 * (size_t)k.nleaf + 2 * (size_t)k.nv * n * n);
+  size_t freeb = 0, totalb = 0;
+  HIP_TRY(c, hipMemGetInfo(&freeb, &totalb));
+  size_t budget = d->max_scratch_bytes > 0 ? (size_t)d->max_scratch_bytes : ((size_t)24 << 30);
+  budget = std::min(budget, freeb / 10 * 7);
+  c->wgroup = (int)std::max<size_t>(1, std::min<size_t>(32, budget / per_walker));
+  // keep conv's grid.z within limits
+  while (c->wgroup > 1 && (long long)c->wgroup * k.nv > 32768) --c->wgroup;
+  c->red_blocks = (int)std::min<long long>(2048, ((long long)ncube + RED_THREADS - 1) / RED_THREADS);
+  const size_t W = c->wgroup;
+  if ((rc = dev_alloc(c, &c->d_wk, W))) return rc;
+  if ((rc = dev_alloc(c, &c->d_params, W * NP))) return rc;
+  if ((rc = dev_alloc(c, &c->d_vl, W * 4 * k.nleaf))) return rc;
+  if ((rc = dev_alloc(c, &c->d_wt, W * 4 * k.nleaf))) return rc;
+  if ((rc = dev_alloc(c, &c->d_iunif, W * k.nv * n * n))) return rc;
+  if ((rc = dev_alloc(c, &c->d_iconv, W * k.nv * n * n))) return rc;
+  if ((rc = dev_alloc(c, &c->d_partial, W * c->red_blocks * 2))) return rc;
+  if ((rc = dev_alloc(c, &c->d_stats, W * 4))) return rc;
+  if ((rc = dev_alloc(c, &c->d_chi2, W))) return rc;
+  HIP_TRY(c, hipStreamCreate(&c->stream));
+  HIP_TRY(c, hipDeviceSynchronize());
+  return SLAMHIP_OK;
+}
+
+void slamhip_destroy(slamhip_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)hipDeviceSynchronize();
+  for (void* p : c->allocs) (void)hipFree(p);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+int slamhip_info(slamhip_ctx* c, int64_t* nleaf, int32_t* wgroup, int32_t* sep) {
+  if (!c) return SLAMHIP_ERR_ARG;
+  if (nleaf) *nleaf = c->k.nleaf;
+  if (wgroup) *wgroup = c->wgroup;
+  if (sep) *sep = c->separable && c->sep_variant >= 0;
+  return SLAMHIP_OK;
+}
+
+int slamhip_set_conv_mode(slamhip_ctx* c, int mode) {
+  if (!c || (mode != 0 && mode != 1)) return SLAMHIP_ERR_ARG;
+  c->conv_mode = mode;
+  return SLAMHIP_OK;
+}
+
+int slamhip_chi2_batch_dev(slamhip_ctx* c, const double* params_dev, int nw,
+                           double* chi2_dev, void* stream) {
+  if (!c || c->wgroup < 1) return SLAMHIP_ERR_STATE;
+  if (nw < 0 || (nw > 0 && (!params_dev || !chi2_dev)))
+    return fail(c, SLAMHIP_ERR_ARG, "chi2_batch_dev: bad arguments");
+  HIP_TRY(c, hipSetDevice(c->device));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  for (int w0 = 0; w0 < nw; w0 += c->wgroup) {
+    const int m = std::min(c->wgroup, nw - w0);
+    int rc = run_group(c, params_dev + (size_t)w0 * NP, m, chi2_dev + w0, st);
+    if (rc) return rc;
+  }
+  return SLAMHIP_OK;
+}
+
+int slamhip_chi2_batch(slamhip_ctx* c, const double* params, int nw, double* chi2_out) {
+  if (!c || c->wgroup < 1) return SLAMHIP_ERR_STATE;
+  if (nw < 0 || (nw > 0 && (!params || !chi2_out)))
+    return fail(c, SLAMHIP_ERR_ARG, "chi2_batch: bad arguments");
+  if (nw == 0) return SLAMHIP_OK;
+  HIP_TRY(c, hipSetDevice(c->device));
+  double *dp = nullptr, *dc = nullptr;
+  HIP_TRY(c, hipMalloc((void**)&dp, (size_t)nw * NP * sizeof(double)));
+  hipError_t e = hipMalloc((void**)&dc, (size_t)nw * sizeof(double));
+  if (e != hipSuccess) { (void)hipFree(dp); return fail(c, SLAMHIP_ERR_NOMEM, "hipMalloc chi2"); }
+  int rc = SLAMHIP_OK;
+  e = hipMemcpyAsync(dp, params, (size_t)nw * NP * sizeof(double), hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) rc = slamhip_chi2_batch_dev(c, dp, nw, dc, c->stream);
+  if (e == hipSuccess && rc == SLAMHIP_OK)
+    e = hipMemcpyAsync(chi2_out, dc, (size_t)nw * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  (void)hipFree(dp);
+  (void)hipFree(dc);
+  if (rc) return rc;
+  if (e != hipSuccess) return fail(c, SLAMHIP_ERR_HIP, "chi2_batch: %s", hipGetErrorString(e));
+  return SLAMHIP_OK;
+}
+
+static int single_prepare(slamhip_ctx* c, const double* params) {
+  if (!c || c->wgroup < 1) return SLAMHIP_ERR_STATE;
+  if (!params) return fail(c, SLAMHIP_ERR_ARG, "null params");
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipMemcpyAsync(c->d_params, params, NP * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  return SLAMHIP_OK;
+}
+
+int slamhip_iunif(slamhip_ctx* c, const double* params, double* out) {
+  int rc = single_prepare(c, params);
+  if (rc) return rc;
+  if ((rc = run_model(c, c->d_params, 1, c->stream))) return rc;
+  const size_t nb = (size_t)c->k.nv * c->k.nneed * c->k.nneed * sizeof(double);
+  HIP_TRY(c, hipMemcpyAsync(out, c->d_iunif, nb, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return SLAMHIP_OK;
+}
+
+int slamhip_iconv(slamhip_ctx* c, const double* params, double* out) {
+  int rc = single_prepare(c, params);
+  if (rc) return rc;
+  if ((rc = run_model(c, c->d_params, 1, c->stream))) return rc;
+  if ((rc = run_conv(c, c->d_iunif, c->d_iconv, c->k.nv, c->stream))) return rc;
+  const size_t nb = (size_t)c->k.nv * c->k.nneed * c->k.nneed * sizeof(double);
+  HIP_TRY(c, hipMemcpyAsync(out, c->d_iconv, nb, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return SLAMHIP_OK;
+}
+
+int slamhip_cubemodel(slamhip_ctx* c, const double* params, int convolving,
+                      double* out, double* stats_out) {
+  int rc = single_prepare(c, params);
+  if (rc) return rc;
+  if (!out) return fail(c, SLAMHIP_ERR_ARG, "null output");
+  const FitK& k = c->k;
+  if ((rc = run_model(c, c->d_params, 1, c->stream))) return rc;
+  if (convolving) {
+    if ((rc = run_conv(c, c->d_iunif, c->d_iconv, k.nv, c->stream))) return rc;
+  } else {
+    hipLaunchKernelGGL(k_peak_unity, dim3(k.nv), dim3(256), 0, c->stream, k, c->d_iunif, c->d_iconv);
+  }
+  const size_t ncube = (size_t)k.nv * k.ny * k.nx;
+  double* d_cube = nullptr;
+  HIP_TRY(c, hipMalloc((void**)&d_cube, ncube * sizeof(double)));
+  hipLaunchKernelGGL((k_regrid<true>), dim3(c->red_blocks, 1, 1), dim3(RED_THREADS), 0, c->stream,
+                     k, c->d_wk, c->d_iconv, c->d_partial, d_cube);
+  hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, c->stream, k, c->d_partial, c->red_blocks,
+                     c->d_stats, (double*)nullptr);
+  hipLaunchKernelGGL(k_scale, dim3(1024), dim3(256), 0, c->stream, d_cube, (long long)ncube, c->d_stats);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess)
+    e = hipMemcpyAsync(out, d_cube, ncube * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess && stats_out)
+    e = hipMemcpyAsync(stats_out, c->d_stats, 4 * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  (void)hipFree(d_cube);
+  if (e != hipSuccess) return fail(c, SLAMHIP_ERR_HIP, "cubemodel: %s", hipGetErrorString(e));
+  return SLAMHIP_OK;
+}
+
+int slamhip_surface(slamhip_ctx* c, const double* params, int slot, double* x_out,
+                    double* v_out) {
+  int rc = single_prepare(c, params);
+  if (rc) return rc;
+  if (slot < 0 || slot > 3 || !x_out || !v_out) return fail(c, SLAMHIP_ERR_ARG, "surface: bad arguments");
+  const FitK& k = c->k;
+  hipLaunchKernelGGL(k_prep, dim3(1), dim3(64), 0, c->stream, k, c->d_params, 1, c->d_wk);
+  WalkerK hw;
+  HIP_TRY(c, hipMemcpyAsync(&hw, c->d_wk, sizeof hw, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  const int s = hw.slot_surf[slot];
+  if (s < 0) return 1;
+  const size_t ngrid = (size_t)k.nlayer * k.npix * k.npix;
+  double* d_buf = nullptr;
+  HIP_TRY(c, hipMalloc((void**)&d_buf, 2 * ngrid * sizeof(double)));
+  hipLaunchKernelGGL(k_surface_tap, dim3((unsigned)((ngrid + 255) / 256)), dim3(256), 0, c->stream,
+                     k, c->d_wk, s, d_buf, d_buf + ngrid);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpyAsync(x_out, d_buf, ngrid * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(v_out, d_buf + ngrid, ngrid * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  (void)hipFree(d_buf);
+  if (e != hipSuccess) return fail(c, SLAMHIP_ERR_HIP, "surface: %s", hipGetErrorString(e));
+  return SLAMHIP_OK;
+}
+
+int slamhip_prof(slamhip_ctx* c, double cs, double* prof_out, double* prof_d_out) {
+  if (!c || c->wgroup < 1) return SLAMHIP_ERR_STATE;
+  double p[NP] = {1, 1, cs, 0, -1, 0, 0, 0, 0, 0, 0, 0, 0};
+  int rc = single_prepare(c, p);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_prep, dim3(1), dim3(64), 0, c->stream, c->k, c->d_params, 1, c->d_wk);
+  WalkerK hw;
+  HIP_TRY(c, hipMemcpyAsync(&hw, c->d_wk, sizeof hw, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (prof_out) std::memcpy(prof_out, hw.prof, sizeof hw.prof);
+  if (prof_d_out) *prof_d_out = hw.prof_d;
+  return SLAMHIP_OK;
+}
+
+}  // extern "C"
