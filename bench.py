@@ -1,0 +1,157 @@
+#!/usr/bin/env python3
+"""Benchmark: batched channelfit log-likelihood (model cube + chi-square) on
+SYN-v1 synthetic cubes.  One "step" = one batched likelihood
+call as the sampler sees it: `--walkers` parameter vectors per GPU in, their
+chi2 out (weak scaling: per-GPU work is fixed as --gpus grows).
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
+        --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK = 8.0e12      # B/s, MI355X spec (MI355X_MICROARCH.md, chip-level parameters)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--config', default='C3', choices=['C2', 'C3', 'C4'])
+    ap.add_argument('--walkers', type=int, default=1024, help='walkers per GPU per step')
+    ap.add_argument('--bpa', type=float, default=0.0, help='beam position angle [deg]; 0 = separable')
+    ap.add_argument('--cpu-evals', type=int, default=1,
+                    help='oracle evaluations timed for cpu_baseline (0 = skip)')
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get('RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    local = int(os.environ.get('LOCAL_RANK', 0))
+    if world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run')
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+
+    from slam_amd import synth
+    from slam_amd.sharding import ShardedLikelihood
+    fit = synth.make_fit(args.config, bpa=args.bpa)
+    eng = fit.engine
+    nw_total = args.walkers * world
+    P = synth.walkers(nw_total) if rank == 0 else None
+    sharded = ShardedLikelihood(eng.chi2_batch_torch, device='cuda')
+    Pd = torch.as_tensor(P, device='cuda') if rank == 0 else None
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        chi2 = sharded.chi2(Pd, nw_total)
+    barrier()
+    eng.profile_begin()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        chi2 = sharded.chi2(Pd, nw_total)
+    barrier()
+    dt = time.perf_counter() - t0
+    kern = eng.profile_end()
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    chi2 = chi2.cpu().numpy()
+
+    if rank == 0:
+        B = 8
+        nv, n, nx, ny = eng.nv, eng.nneed, eng.nx, eng.ny
+        bytes_eval = synth.bytes_per_eval(fit, B)
+        # algorithmic bytes per walker of each kernel (SURVEY.md 8d's four stages)
+        alg = {'k_profile': B * nv * n * n,
+               'k_conv': 2 * B * nv * n * n,
+               'k_regrid': B * nv * (n * n + nx * ny)}
+        evals_rank = args.walkers * args.steps
+        total_ms = sum(v[0] for v in kern.values())
+        per_kernel = {}
+        for name, (ms, cnt) in kern.items():
+            if cnt == 0:
+                continue
+            d = {'ms_per_launch': ms / cnt, 'launches': cnt, 'ms_per_eval': ms / evals_rank,
+                 'share': ms / total_ms}
+            if name in alg:
+                d['achieved_GBps'] = alg[name] * evals_rank / (ms * 1e-3) / 1e9
+                d['frac'] = d['achieved_GBps'] * 1e9 / HBM_PEAK
+            per_kernel[name] = d
+        dom = max(alg, key=lambda k: kern[k][0])
+        ms, cnt = kern[dom]
+        achieved = alg[dom] * evals_rank / (ms * 1e-3)
+        roofline = {
+            'bound': 'hbm', 'kernel': dom,
+            'achieved': achieved / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
+            'frac': achieved / HBM_PEAK, 'traffic': None,
+            'bytes_per_launch': alg[dom] * evals_rank / cnt,
+            'ms_per_launch': ms / cnt, 'launches': cnt,
+            'pipeline': {'bytes_per_eval': bytes_eval,
+                         'achieved': bytes_eval * evals_rank / dt / 1e9,
+                         'frac': bytes_eval * evals_rank / dt / HBM_PEAK,
+                         'kernel_ms_per_eval': total_ms / evals_rank},
+            'per_kernel': per_kernel,
+        }
+        out = {
+            'metric': 'walker chi2 evals/sec (whole node) at 512x512x128'
+                      if args.config == 'C3' else f'walker chi2 evals/sec (whole node), {args.config}',
+            'value': nw_total * args.steps / dt, 'unit': 'evals/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': f'SYN-v1 {args.config}: {nx}x{ny}x{nv} cube, '
+                                   f'{args.walkers} walkers per GPU per step, beam K={fit.gaussbeam.shape[0]} '
+                                   f'bpa={args.bpa:g} ({"separable" if eng.separable_beam else "direct 2-D"})',
+                       'walkers_per_gpu': args.walkers, 'walkers_per_launch': eng.walkers_per_group,
+                       'npix': eng.npix, 'nneed': n, 'nleaf': eng.nleaf,
+                       'chi2_checksum': float(np.sum(chi2))},
+            'roofline': roofline,
+        }
+        if world == 1 and args.cpu_evals > 0:
+            out['cpu_baseline'] = cpu_baseline(fit, P, chi2, args.cpu_evals)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(fit, P, chi2_gpu, nevals):
+    """Time the CPU oracle (numpy/scipy restatement of the reference path) on
+    the first `nevals` walkers of the same workload, one process, one core."""
+    from oracle import channelfit_oracle as orc
+    from slam_amd import synth
+    s = orc.make_setup(fit.x, fit.y, fit.v, fit.data, bmaj=fit.bmaj, bmin=fit.bmin,
+                       bpa=fit.bpa, sigma=fit.sigma, pa=2.0, incl=60.0, rmax=synth.RMAX,
+                       signmajor=1, signminor=1)
+    t0 = time.perf_counter()
+    ref = np.array([orc.chi2_of(s, P[i]) for i in range(nevals)])
+    dt = time.perf_counter() - t0
+    err = float(np.max(np.abs(ref - chi2_gpu[:nevals]) / np.abs(ref)))
+    return {'value': nevals / dt, 'unit': 'evals/s', 'cores': 1, 'kind': 'port',
+            'sample': f'first {nevals} of the {len(P)} walkers, full cube, '
+                      'oracle/channelfit_oracle.py (numpy+scipy, single process)',
+            'seconds': dt, 'max_rel_err_vs_gpu': err}
+
+
+if __name__ == '__main__':
+    main()

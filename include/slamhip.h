@@ -122,6 +122,15 @@ int slamhip_info(slamhip_ctx* ctx, int64_t* nleaf, int32_t* walkers_per_group,
  * outer product to 1e-14, else direct 2-D), 1 = force direct 2-D. */
 int slamhip_set_conv_mode(slamhip_ctx* ctx, int mode);
 
+/* Measurement aid (no counterpart in the reference): between _begin and _end
+ * every kernel launch of this context is bracketed by HIP events recorded on
+ * the stream it is launched on.  _end waits for them and returns, per kernel
+ * id 0..slamhip_kernel_count()-1, the summed duration [ms] and launch count. */
+int slamhip_kernel_count(void);
+const char* slamhip_kernel_name(int i);
+int slamhip_profile_begin(slamhip_ctx* ctx);
+int slamhip_profile_end(slamhip_ctx* ctx, double* total_ms, int64_t* launches);
+
 const char* slamhip_last_error(slamhip_ctx* ctx);
 void slamhip_destroy(slamhip_ctx* ctx);
 

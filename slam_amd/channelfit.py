@@ -1,0 +1,388 @@
+"""Drop-in `ChannelFit` whose likelihood runs on the MI355X.
+
+Same constructor, `makegrid`, `fitting`, `cubemodel`, `modeltofits`, `plotmom`
+signatures and result attributes (`popt/plow/pmid/phigh` dicts, `chi2r`,
+`<filename>.popt.txt`) as the reference class
+(jinshisai/SLAM `channelfit/_channelfit.py:212-792`).  What changes:
+
+* `makegrid` (host, numpy, once per fit) ends by uploading its constants to the
+  GPU (`HipLikelihood`, libslamhip.so).
+* `fitting` hands the sampler a BATCHED log-probability: one C-ABI call per
+  half-ensemble instead of one Python `cubemodel` call per walker (:594-603).
+* `cubemodel` is one C-ABI call (:499-537).
+
+Only `scaling='uniform'` is implemented on the GPU (SURVEY.md section 8f lists
+the `mom0*` variants as next); anything else raises NotImplementedError rather
+than silently taking another path.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .engine import PARAMKEYS, HipLikelihood
+from .utils import ReadFits, emcee_corner, rot
+
+# astropy.constants / units values the reference reads at import (:29-32):
+# CODATA 2018 G, IAU 2015 nominal GM_sun / G, the au in metres.
+_G = 6.6743e-11
+_MSUN = 1.3271244e20 / 6.6743e-11
+_AU = 149597870700.0
+vunit = np.sqrt(_G * _MSUN / _AU) * 1e-3
+
+_UNITS = ['Msun', 'au', 'km/s', '', '', '', 'au', '', 'au', 'au', 'km/s',
+          'deg', 'deg']
+_DIGITS = [2, 0, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2]
+_ILOG = np.array([0, 1, 7])          # Mstar, Rc, Ienv are sampled in log10 (:578)
+
+
+def makemom01(d, v, sigma):
+    """Moment 0/1 maps of a cube (:40-50)."""
+    with np.errstate(all='ignore'):
+        dv = np.min(v[1:] - v[:-1])
+        mom0 = np.sum(d, axis=0) * dv
+        sigma_mom0 = sigma * dv * np.sqrt(len(d))
+        vv = np.asarray(v)[:, None, None]
+        mom1 = np.sum(d * vv, axis=0) / np.sum(d, axis=0)
+        mom2 = np.sqrt(np.sum(d * (vv - mom1)**2, axis=0), np.sum(d, axis=0))
+        mom1[mom0 < 3 * sigma_mom0] = np.nan
+    return {'mom0': mom0, 'mom1': mom1, 'mom2': mom2, 'sigma_mom0': sigma_mom0}
+
+
+class ChannelFit(ReadFits):
+
+    def __init__(self, disk: bool = True, envelope: bool = False,
+                 scaling: str = 'uniform', progressbar: bool = True):
+        self.paramkeys = list(PARAMKEYS)
+        self.disk = disk
+        self.envelope = envelope
+        self.scaling = scaling
+        self.progressbar = progressbar
+        self.engine = None
+        if scaling != 'uniform':
+            raise NotImplementedError(
+                f"scaling='{scaling}': only 'uniform' runs on the GPU path")
+
+    # -- synthetic / in-memory input (extension; the reference reads FITS only)
+    def set_cube(self, x, y, v, data, bmaj, bmin, bpa, sigma):
+        """Provide the cube as arrays instead of a FITS file; then call
+        `makegrid(cubefits=None, ...)`.  x, y in au, v in km/s relative to vsys."""
+        self.x, self.y, self.v = (np.asarray(a, dtype=float) for a in (x, y, v))
+        self.dx, self.dy, self.dv = (self.x[1] - self.x[0], self.y[1] - self.y[0],
+                                     self.v[1] - self.v[0])
+        self.nx, self.ny, self.nv = len(self.x), len(self.y), len(self.v)
+        self.data = np.asarray(data)
+        self.bmaj, self.bmin, self.bpa = float(bmaj), float(bmin), float(bpa)
+        self.sigma = float(sigma)
+        self.offpix = (0, 0, 0)
+
+    def makegrid(self, cubefits: str | None = None,
+                 pa: float = 0, incl: float = 90, dist: float = 1,
+                 center: str | None = None, vsys: float = 0,
+                 rmax: float = 1e4,
+                 vlim: tuple = (-100, 0, 0, 100),
+                 sigma: float | None = None, nlayer: int = 3,
+                 xskip: int = 1, yskip: int = 1, skipto: int | None = False,
+                 gaussmargin: float = 1.6,
+                 savedeconvolved: str | None = None,
+                 loaddeconvolved: str | None = None,
+                 signmajor: int | None = None,
+                 signminor: int | None = None,
+                 max_scratch_bytes: int = 0):
+        """One-time setup (:227-341), then upload to the GPU."""
+        if cubefits is not None:
+            self.read_cubefits(cubefits, center, dist, vsys, -rmax, rmax,
+                               -rmax, rmax, None, None, xskip, yskip, sigma)
+            if type(skipto) is int:                                  # :244-256
+                dpix = min(abs(self.dx), abs(self.dy))
+                iskip = int(self.bmin / (dpix / xskip) / skipto)
+                if iskip == 0:
+                    print("WARNING: 'skipto' is ignored because the beam minor"
+                          " axis is smaller than 'skipto' pixels.")
+                    iskip = 1
+                self.read_cubefits(cubefits, center, dist, vsys, -rmax, rmax,
+                                   -rmax, rmax, None, None, iskip, iskip, sigma)
+                dpix = min(abs(self.dx), abs(self.dy))
+                print(f'Adopt xskip={iskip:d} and yskip={iskip:d}.')
+                print(f'Beam major/minor axis is {self.bmaj / dpix:.1f}'
+                      f'/{self.bmin / dpix:.1f} pixels.')
+        elif not hasattr(self, 'data'):
+            raise ValueError('makegrid needs cubefits=... or a prior set_cube()')
+        if sigma is None:
+            sigma = self.sigma
+        self.sigma = sigma
+        dpix = min(abs(self.dx), abs(self.dy))
+        v = self.v
+        self.incl0 = incl
+        self.pa_rad = np.radians(pa)
+        self.cospa, self.sinpa = np.cos(self.pa_rad), np.sin(self.pa_rad)
+        self.X, self.Y = np.meshgrid(self.x, self.y)
+
+        # velocity windows (:265-274)
+        in_blue = (vlim[0] <= v) * (v <= vlim[1])
+        in_red = (vlim[2] <= v) * (v <= vlim[3])
+        self.v_nanblue = v[v < vlim[0]]
+        self.v_blue = v[in_blue]
+        self.v_nanmid = v[(vlim[1] < v) * (v < vlim[2])]
+        self.v_red = v[in_red]
+        self.v_nanred = v[vlim[3] < v]
+        self.v_valid = np.r_[self.v_blue, self.v_red]
+        self.data_blue = self.data[in_blue]
+        self.data_red = self.data[in_red]
+        self.data_valid = np.append(self.data_blue, self.data_red, axis=0)
+        print(f'{len(self.v_valid):d} channels will be fitted.')
+
+        # rotation signs from the moment-1 map (:276-289)
+        m = makemom01(self.data_valid, self.v_valid, sigma)
+        self.mom0, self.mom1, self.mom2 = m['mom0'], m['mom1'], m['mom2']
+        self.sigma_mom0 = m['sigma_mom0']
+        Xr, Yr = rot(self.X, self.Y, self.pa_rad)
+        self.signmajor = (np.sign(np.nansum(self.mom1 * Yr))
+                          if signmajor is None else signmajor)
+        self.signminor = (np.sign(np.nansum(self.mom1 * Xr)) * (-1)
+                          if signminor is None else signminor)
+
+        # nested grid on the disk plane (:293-320)
+        r_need = rmax + gaussmargin * self.bmaj
+        npix = int(2 * r_need / dpix + 0.5)
+        npix = int(4 * np.ceil(npix / 4))
+        self.npix = npix
+        self.nq1 = npix // 2 - npix // 2 // 2
+        self.nq3 = self.nq1 + npix // 2
+        self.nlayer = nlayer
+        half = npix // 2 - 0.5
+        self.xnest = np.array([np.linspace(-half, half, npix) * dpix / 2**l
+                               for l in range(nlayer)])
+        self.ynest = self.xnest.copy()
+        Xn = np.array([np.meshgrid(s, s)[0] for s in self.xnest])
+        Yn = np.array([np.meshgrid(s, s)[1] for s in self.xnest])
+        self.Xnest, self.Ynest = rot(Xn, Yn, self.pa_rad)
+        self.Xnest0, self.Ynest0 = self.Xnest * 1, self.Ynest * 1
+        print('-------- nested grid --------')
+        for s in self.xnest:
+            print(f'x, dx, npix: +/-{s[-1]:.2f}, {s[1] - s[0]:.2f} au, {npix:d}')
+        print('-----------------------------')
+
+        # beam kernel on the model grid (:329-335)
+        ngauss = int(gaussmargin * self.bmaj / dpix + 0.5)
+        t = (np.arange(2 * ngauss + 1) - ngauss) * dpix
+        xb, yb = rot(*np.meshgrid(t, t), np.radians(self.bpa))
+        self.gaussbeam = np.exp2(-4 * ((yb / self.bmaj)**2 + (xb / self.bmin)**2))
+        self.pixperbeam = np.sum(self.gaussbeam)
+
+        # crop (:337-341)
+        n_need = int(r_need / dpix + 0.5)
+        self.ineed0 = npix // 2 - n_need
+        self.ineed1 = npix // 2 + n_need
+        self.xneed = self.xnest[0][self.ineed0:self.ineed1]
+        self.yneed = self.ynest[0][self.ineed0:self.ineed1]
+
+        if self.engine is not None:
+            self.engine.close()
+        self.engine = HipLikelihood(self.setup_dict(),
+                                    max_scratch_bytes=max_scratch_bytes)
+
+    def setup_dict(self):
+        """The constants libslamhip.so needs (slamhip_desc)."""
+        keys = ('nlayer', 'npix', 'nq1', 'nq3', 'ineed0', 'ineed1', 'dv',
+                'sigma', 'pixperbeam', 'incl0', 'signmajor', 'signminor',
+                'disk', 'envelope', 'Xnest0', 'Ynest0', 'xneed', 'yneed', 'x',
+                'y', 'v_valid', 'data_valid', 'gaussbeam')
+        d = {k: getattr(self, k) for k in keys}
+        d['vunit'] = vunit
+        return d
+
+    # -- forward model -------------------------------------------------------
+    def _natural(self, Mstar, Rc, cs, h1, h2, pI, Rin, Ienv, xoff, yoff, voff,
+                 incloff, paoff):
+        return np.array([Mstar, Rc, cs, h1, h2, pI, Rin, Ienv, xoff, yoff,
+                         voff, incloff, paoff], dtype=float)
+
+    def cubemodel(self, Mstar: float, Rc: float, cs: float,
+                  h1: float = 0, h2: float = -1, pI: float = 0,
+                  Rin: float = 0, Ienv: float = 0,
+                  xoff: float = 0, yoff: float = 0, voff: float = 0,
+                  incloff: float = 90, paoff: float = 0,
+                  convolving: bool = True):
+        """Model cube (nv_valid, ny, nx), least-squares scaled (:499-537)."""
+        p = self._natural(Mstar, Rc, cs, h1, h2, pI, Rin, Ienv, xoff, yoff,
+                          voff, incloff, paoff)
+        return self.engine.cubemodel(p, convolving=convolving)
+
+    def chi2_batch(self, P):
+        """chi2 (:601-602) for natural-unit parameter rows P[nw, 13]."""
+        return self.engine.chi2_batch(P)
+
+    # -- fit driver ----------------------------------------------------------
+    def fitting(self, Mstar_range: list = [0.01, 10],
+                Rc_range: list = [1, 1000],
+                cs_range: list = [0.01, 1],
+                h1_range: list = [0.01, 1],
+                h2_range: list = [0.01, 1],
+                pI_range: list = [-2, 2],
+                Rin_range: list = [0, 1000],
+                Ienv_range: list = [0.01, 100],
+                xoff_range: list = [-100, 100],
+                yoff_range: list = [-100, 100],
+                voff_range: list = [-0.2, 0.2],
+                incl_range: list = [-45, 45],
+                pa_range: list = [-45, 45],
+                fixed_params: dict = {},
+                filename: str = 'channelfit',
+                show: bool = False,
+                kwargs_emcee_corner: dict = {}):
+        """Free/fixed bookkeeping, log10 sampling of Mstar/Rc/Ienv, sampler
+        call, result table (:539-663).  The sampler receives a vectorised
+        log-probability: p[nw, ndim] -> lnp[nw]."""
+        fixed = [fixed_params.get(k) for k in self.paramkeys]
+        self.free = {k: f is None for k, f in zip(self.paramkeys, fixed)}
+        notfixed = np.array([f is None for f in fixed])
+        runfit = bool(notfixed.any())
+        base = np.array([np.nan if f is None else float(f) for f in fixed])
+        if runfit:
+            logfixed = _ILOG[~notfixed[_ILOG]]
+            with np.errstate(all='ignore'):
+                base[logfixed] = np.log10(base[logfixed])            # :580
+            labels = np.array(self.paramkeys).copy()
+            labels[_ILOG] = ['log' + labels[i] for i in _ILOG]
+            labels = labels[notfixed]
+            kw = {'nwalkers_per_ndim': 16, 'nburnin': 200, 'nsteps': 500,
+                  'labels': labels, 'rangelevel': None, 'range_corner': None,
+                  'figname': filename + '.corner.png', 'show_corner': show}
+            kw.update(kwargs_emcee_corner)
+            bar = None
+            if self.progressbar:
+                from tqdm import tqdm
+                total = kw['nwalkers_per_ndim'] * int(notfixed.sum())
+                total *= kw['nburnin'] + kw['nsteps'] + 2
+                bar = tqdm(total=total)
+                bar.set_description('Within the ranges')
+
+            def to_natural(P):
+                """sampled vectors [nw, ndim] -> natural 13-vectors (:597-599)"""
+                P = np.atleast_2d(np.asarray(P, dtype=float))
+                Q = np.tile(base, (len(P), 1))
+                Q[:, notfixed] = P
+                Q[:, _ILOG] = 10**Q[:, _ILOG]
+                return Q
+
+            def lnprob(P):
+                single = np.ndim(P) == 1
+                Q = to_natural(P)
+                if bar is not None:
+                    bar.update(len(Q))
+                lnp = -0.5 * self.engine.chi2_batch(Q)               # :601-603
+                return lnp[0] if single else lnp
+
+            self.lnprob = lnprob
+            self.to_natural = to_natural
+            plim = np.array([Mstar_range, Rc_range, cs_range, h1_range,
+                             h2_range, pI_range, Rin_range, Ienv_range,
+                             xoff_range, yoff_range, voff_range,
+                             incl_range, pa_range], dtype=float)
+            with np.errstate(all='ignore'):
+                plim[_ILOG] = np.log10(plim[_ILOG])
+            plim = plim[notfixed].T
+            if type(r_c := kw['range_corner']) is dict:                # :611-616
+                r_c = [r_c[k] if k in r_c else 0.8 for k in self.paramkeys]
+                for i in _ILOG:
+                    r_c[i] = r_c[i] if type(r_c[i]) is float else np.log10(r_c[i])
+                kw['range_corner'] = [a for a, k in zip(r_c, self.paramkeys)
+                                      if self.free[k]]
+            self.plim = plim
+            mcmc = emcee_corner(plim, lnprob, simpleoutput=False,
+                                vectorize=True, **kw)
+            if bar is not None:
+                bar.close()
+            res = [to_natural(m)[0] for m in mcmc]
+            self.popt, self.plow, self.pmid, self.phigh = res
+        else:
+            chi2 = self.engine.chi2_batch(base[None])[0]               # :629-634
+            dof = np.prod(np.shape(self.data_valid))
+            dof = dof / self.pixperbeam - 6 - 1
+            self.chi2r = chi2 / dof
+            self.popt = self.plow = self.pmid = self.phigh = base
+
+        self.pa_rad = self.pa_rad + np.radians(self.popt[12])           # :645-647
+        self.sinpa, self.cospa = np.sin(self.pa_rad), np.cos(self.pa_rad)
+        for i, (k, d, u) in enumerate(zip(self.paramkeys, _DIGITS, _UNITS)):
+            p = [self.plow[i], self.popt[i], self.phigh[i]]
+            print(f'{k} = {p[0]:.{d:d}f}, {p[1]:.{d:d}f}, {p[2]:.{d:d}f} {u}')
+        if runfit:
+            with open(filename + '.popt.txt', 'w') as f:               # :654-659
+                f.write('#Rows:' + ','.join(self.paramkeys) + '\n')
+                f.write('#Columns:' + ','.join(['popt', 'plow', 'pmid', 'phigh']) + '\n')
+                np.savetxt(f, np.transpose([self.popt, self.plow, self.pmid,
+                                            self.phigh]))
+        self.popt = dict(zip(self.paramkeys, self.popt))
+        self.plow = dict(zip(self.paramkeys, self.plow))
+        self.pmid = dict(zip(self.paramkeys, self.pmid))
+        self.phigh = dict(zip(self.paramkeys, self.phigh))
+
+    # -- outputs -------------------------------------------------------------
+    def _full_velocity_cube(self, m):
+        """Valid-channel cube -> full velocity axis, NaN where not fitted
+        (`concat` in :682-705)."""
+        full = np.full((len(self.v), len(self.y), len(self.x)), np.nan)
+        vv = np.asarray(self.v)
+        for k, vk in enumerate(self.v_valid):
+            full[np.where(vv == vk)[0][0]] = m[k]
+        return full
+
+    def modeltofits(self, filehead: str = 'best', **kwargs):
+        """Write model / residual / unconvolved cubes as FITS (:665-718)."""
+        from .fitsio import write_cube
+        p = self.popt if kwargs == {} else kwargs
+        for k in self.free.keys():
+            self.free[k] = True
+        m = self.cubemodel(**p)
+        m0 = self.cubemodel(**p, convolving=False)
+        h = dict(self.header)
+        h['NAXIS1'], h['NAXIS2'], h['NAXIS3'] = len(self.x), len(self.y), len(self.v)
+        for ax in (1, 2, 3):
+            h[f'CRPIX{ax}'] = h[f'CRPIX{ax}'] - self.offpix[ax - 1]
+        model = self._full_velocity_cube(m)
+        write_cube(f'{filehead}.model.fits', model, h)
+        write_cube(f'{filehead}.residual.fits', self.data - model, h)
+        write_cube(f'{filehead}.beforeconvolving.fits',
+                   self._full_velocity_cube(m0), h)
+
+    def plotmom(self, mode: str, filename: str = 'mom01.png', **kwargs):
+        """Moment 0/1 figure of the observation, model or residual (:720-762)."""
+        import matplotlib
+        matplotlib.use('Agg', force=False)
+        import matplotlib.pyplot as plt
+        from matplotlib.patches import Ellipse
+        if 'mod' in mode or 'res' in mode or 'clean' in mode:
+            if kwargs != {}:
+                self.popt = kwargs
+            m = makemom01(self.cubemodel(**self.popt), self.v_valid, self.sigma)
+        if 'obs' in mode:
+            mom0, mom1, label = self.mom0, self.mom1, 'Obs.'
+        elif 'mod' in mode:
+            mom0, mom1, label = m['mom0'], m['mom1'], 'Model'
+        elif 'res' in mode:
+            mom0, mom1 = self.mom0 - m['mom0'], self.mom1 - m['mom1']
+            label = r'Obs. $-$ model'
+        levels = (3 if 'res' in mode else 6) * self.sigma_mom0
+        levels = np.arange(1, 20) * levels
+        levels = np.sort(np.r_[-levels, levels])
+        fig = plt.figure()
+        ax = fig.add_subplot(1, 1, 1)
+        vplot = (np.nanpercentile(self.mom1, 99) - np.nanpercentile(self.mom1, 1)) / 2.
+        im = ax.pcolormesh(self.x, self.y, mom1, cmap='jet', shading='nearest',
+                           vmin=-vplot, vmax=vplot)
+        fig.colorbar(im, ax=ax, label=label + r' mom1 (km s$^{-1}$)')
+        ax.contour(self.x, self.y, mom0, colors='gray', levels=levels)
+        r = np.linspace(-1, 1, 3) * self.x.max() * 1.42
+        ax.plot(r * self.sinpa, r * self.cospa, 'k:')
+        ax.plot(r * self.cospa, -r * self.sinpa, 'k:')
+        bpos = np.max(self.x) - 0.7 * self.bmaj
+        ax.add_patch(Ellipse((bpos, -bpos), width=self.bmin, height=self.bmaj,
+                             angle=self.bpa * np.sign(self.dx), facecolor='gray'))
+        ax.set_xlabel('R.A. offset (au)')
+        ax.set_ylabel('Dec. offset (au)')
+        ax.set_xlim(self.x.max() * 1.01, self.x.min() * 1.01)
+        ax.set_ylim(self.y.min() * 1.01, self.y.max() * 1.01)
+        ax.set_aspect(1)
+        fig.savefig(filename)
+        plt.close()

@@ -658,6 +658,27 @@ struct slamhip_ctx {
   int sep_variant = 0;     // 0: <64,3>  1: <64,5>  2: <32,4>  -1: none fits
   size_t sep_lds = 0, c2d_lds = 0;
   hipStream_t stream = nullptr;
+  // optional per-kernel HIP-event timing (slamhip_profile_begin/_end)
+  bool profiling = false;
+  struct Span { int kid; hipEvent_t a, b; };
+  std::vector<Span> spans;
+};
+
+enum KernelId { KID_PREP = 0, KID_SURFACE, KID_PROFILE, KID_CONV, KID_REGRID, KID_FINALIZE, KID_COUNT };
+static const char* const kKernelNames[KID_COUNT] = {
+    "k_prep", "k_surface", "k_profile", "k_conv", "k_regrid", "k_finalize"};
+
+// Brackets one launch with events on the launch stream when profiling is on.
+struct Timed {
+  slamhip_ctx* c; hipStream_t st; hipEvent_t b = nullptr; bool on;
+  Timed(slamhip_ctx* c_, int kid, hipStream_t st_) : c(c_), st(st_), on(c_->profiling) {
+    if (!on) return;
+    hipEvent_t a = nullptr;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { on = false; return; }
+    (void)hipEventRecord(a, st);
+    c->spans.push_back({kid, a, b});
+  }
+  ~Timed() { if (on) (void)hipEventRecord(b, st); }
 };
 
 namespace {
@@ -757,6 +778,7 @@ int run_conv(slamhip_ctx* c, const double* in, double* out, int planes,
     const int np_ = std::min(32768, planes - p0);
     const double* src = in + (long long)p0 * n * n;
     double* dst = out + (long long)p0 * n * n;
+    Timed t_(c, KID_CONV, st);
     if (sep) {
       switch (c->sep_variant) {
         case 0: launch_conv_sep<64, 3>(c, src, dst, np_, st); break;
@@ -778,12 +800,21 @@ int run_conv(slamhip_ctx* c, const double* in, double* out, int planes,
 // Stages shared by every entry point: params (device) -> iunif for `nw` walkers
 int run_model(slamhip_ctx* c, const double* d_params, int nw, hipStream_t st) {
   const FitK& k = c->k;
-  hipLaunchKernelGGL(k_prep, dim3(nw), dim3(64), 0, st, k, d_params, nw, c->d_wk);
-  dim3 g1((unsigned)((k.nleaf + 255) / 256), 1, nw);
-  hipLaunchKernelGGL(k_surface, g1, dim3(256), 0, st, k, c->d_wk, c->d_vl, c->d_wt);
-  dim3 g2((k.nneed * k.nneed + 255) / 256, 1, nw);
-  hipLaunchKernelGGL(k_profile, g2, dim3(256), 0, st, k, c->d_wk, c->d_vl, c->d_wt,
-                     c->d_iunif);
+  {
+    Timed t_(c, KID_PREP, st);
+    hipLaunchKernelGGL(k_prep, dim3(nw), dim3(64), 0, st, k, d_params, nw, c->d_wk);
+  }
+  {
+    Timed t_(c, KID_SURFACE, st);
+    dim3 g1((unsigned)((k.nleaf + 255) / 256), 1, nw);
+    hipLaunchKernelGGL(k_surface, g1, dim3(256), 0, st, k, c->d_wk, c->d_vl, c->d_wt);
+  }
+  {
+    Timed t_(c, KID_PROFILE, st);
+    dim3 g2((k.nneed * k.nneed + 255) / 256, 1, nw);
+    hipLaunchKernelGGL(k_profile, g2, dim3(256), 0, st, k, c->d_wk, c->d_vl, c->d_wt,
+                       c->d_iunif);
+  }
   HIP_TRY(c, hipGetLastError());
   return SLAMHIP_OK;
 }
@@ -794,11 +825,17 @@ int run_group(slamhip_ctx* c, const double* d_params, int nw, double* d_chi2,
   if (rc) return rc;
   rc = run_conv(c, c->d_iunif, c->d_iconv, nw * c->k.nv, st);
   if (rc) return rc;
-  dim3 g4(c->red_blocks, 1, nw);
-  hipLaunchKernelGGL((k_regrid<false>), g4, dim3(RED_THREADS), 0, st, c->k, c->d_wk,
-                     c->d_iconv, c->d_partial, (double*)nullptr);
-  hipLaunchKernelGGL(k_finalize, dim3(nw), dim3(64), 0, st, c->k, c->d_partial,
-                     c->red_blocks, c->d_stats, d_chi2);
+  {
+    Timed t_(c, KID_REGRID, st);
+    dim3 g4(c->red_blocks, 1, nw);
+    hipLaunchKernelGGL((k_regrid<false>), g4, dim3(RED_THREADS), 0, st, c->k, c->d_wk,
+                       c->d_iconv, c->d_partial, (double*)nullptr);
+  }
+  {
+    Timed t_(c, KID_FINALIZE, st);
+    hipLaunchKernelGGL(k_finalize, dim3(nw), dim3(64), 0, st, c->k, c->d_partial,
+                       c->red_blocks, c->d_stats, d_chi2);
+  }
   HIP_TRY(c, hipGetLastError());
   return SLAMHIP_OK;
 }
@@ -974,6 +1011,38 @@ int slamhip_info(slamhip_ctx* c, int64_t* nleaf, int32_t* wgroup, int32_t* sep) 
   if (wgroup) *wgroup = c->wgroup;
   if (sep) *sep = c->separable && c->sep_variant >= 0;
   return SLAMHIP_OK;
+}
+
+int slamhip_kernel_count(void) { return KID_COUNT; }
+
+const char* slamhip_kernel_name(int i) {
+  return (i >= 0 && i < KID_COUNT) ? kKernelNames[i] : "";
+}
+
+int slamhip_profile_begin(slamhip_ctx* c) {
+  if (!c) return SLAMHIP_ERR_ARG;
+  for (auto& sp : c->spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
+  c->spans.clear();
+  c->profiling = true;
+  return SLAMHIP_OK;
+}
+
+int slamhip_profile_end(slamhip_ctx* c, double* total_ms, int64_t* launches) {
+  if (!c || !total_ms || !launches) return SLAMHIP_ERR_ARG;
+  c->profiling = false;
+  for (int i = 0; i < KID_COUNT; ++i) { total_ms[i] = 0.0; launches[i] = 0; }
+  int rc = SLAMHIP_OK;
+  for (auto& sp : c->spans) {
+    float ms = 0.f;
+    hipError_t e = hipEventSynchronize(sp.b);
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, sp.a, sp.b);
+    if (e == hipSuccess) { total_ms[sp.kid] += ms; launches[sp.kid] += 1; }
+    else rc = fail(c, SLAMHIP_ERR_HIP, "profile_end: %s", hipGetErrorString(e));
+    (void)hipEventDestroy(sp.a);
+    (void)hipEventDestroy(sp.b);
+  }
+  c->spans.clear();
+  return rc;
 }
 
 int slamhip_set_conv_mode(slamhip_ctx* c, int mode) {

@@ -188,6 +188,21 @@ class HipLikelihood:
                                            C.byref(d)), 'prof')
         return p, d.value
 
+    # -- measurement -------------------------------------------------------
+    def profile_begin(self):
+        self._check(self._lib.slamhip_profile_begin(self._ctx), 'profile_begin')
+
+    def profile_end(self):
+        """{kernel name: (total ms, launches)} since profile_begin (HIP events
+        on the launch stream)."""
+        n = self._lib.slamhip_kernel_count()
+        ms = np.zeros(n, dtype=np.float64)
+        cnt = (C.c_int64 * n)()
+        self._check(self._lib.slamhip_profile_end(self._ctx, as_dp(ms), cnt),
+                    'profile_end')
+        return {self._lib.slamhip_kernel_name(i).decode(): (float(ms[i]), int(cnt[i]))
+                for i in range(n)}
+
     def set_conv_mode(self, mode):
         self._check(self._lib.slamhip_set_conv_mode(self._ctx, int(mode)),
                     'set_conv_mode')

@@ -1,0 +1,85 @@
+"""SYN-v1 synthetic channel-map cubes and walker sets.
+
+The reference ships no cube (`testfits/test.cube.fits` is absent from the
+checkout), so benchmarks and large-size tests use cubes of the named shapes
+generated here: a Keplerian-disk truth model (from this package's own GPU
+`cubemodel`) scaled to 50 sigma at peak plus seeded Gaussian noise.
+"""
+from __future__ import annotations
+
+import contextlib
+import io
+
+import numpy as np
+
+CONFIGS = {
+    # name: (N, NV, beam major px, beam minor px)
+    'C2': (256, 64, 8, 6),
+    'C3': (512, 128, 8, 6),
+    'C4': (1024, 256, 24, 18),
+}
+TRUTH = dict(Mstar=0.5, Rc=150., cs=0.3, h1=0.1, h2=0.3, pI=1., Rin=0., Ienv=0.,
+             xoff=0., yoff=0., voff=0., incloff=0., paoff=0.)
+SIGMA = 1.7e-3
+RMAX = 200.0
+
+
+def axes(N, NV):
+    dpix = 2 * RMAX / N
+    x = -(np.arange(N) - N / 2) * dpix        # descending, like R.A.
+    y = (np.arange(N) - N / 2) * dpix
+    v = (np.arange(NV) - NV / 2 + 0.5) * 0.125
+    return x, y, v, dpix
+
+
+def make_fit(config='C3', bpa=0.0, seed=12345, N=None, NV=None, beam_px=None,
+             verbose=False, max_scratch_bytes=0):
+    """Return a `ChannelFit` with a SYN-v1 cube loaded and `makegrid` done."""
+    from .channelfit import ChannelFit
+    n, nv, bmaj_px, bmin_px = CONFIGS[config] if config in CONFIGS else (N, NV, *beam_px)
+    if N is not None:
+        n = N
+    if NV is not None:
+        nv = NV
+    if beam_px is not None:
+        bmaj_px, bmin_px = beam_px
+    x, y, v, dpix = axes(n, nv)
+    sink = contextlib.nullcontext() if verbose else contextlib.redirect_stdout(io.StringIO())
+    kw = dict(pa=2.0, incl=60.0, rmax=RMAX, signmajor=1, signminor=1,
+              max_scratch_bytes=max_scratch_bytes)
+    with sink:
+        # pass 1: data = 1 everywhere only to obtain a positively scaled truth
+        fit = ChannelFit(progressbar=False)
+        fit.set_cube(x, y, v, np.ones((nv, n, n)), bmaj_px * dpix, bmin_px * dpix,
+                     bpa, SIGMA)
+        fit.makegrid(cubefits=None, **kw)
+        truth = fit.cubemodel(**TRUTH)
+        truth *= 50 * SIGMA / truth.max()
+        rng = np.random.default_rng(seed)
+        data = truth + rng.normal(0.0, SIGMA, truth.shape)
+        fit.engine.close()
+        fit.set_cube(x, y, v, data, bmaj_px * dpix, bmin_px * dpix, bpa, SIGMA)
+        fit.makegrid(cubefits=None, **kw)
+    return fit
+
+
+def walkers(nw, seed=2024):
+    """Natural-unit parameter rows [nw, 13]: (log Mstar, log Rc, h1, h2, pI)
+    uniform in the example's priors (reference example_channelfit.py:22-32),
+    cs = 0.4, everything else 0."""
+    u = np.random.default_rng(seed).random((nw, 5))
+    P = np.zeros((nw, 13))
+    P[:, 0] = 10**(np.log10(0.1) + u[:, 0] * (np.log10(1.0) - np.log10(0.1)))
+    P[:, 1] = 10**(np.log10(30.) + u[:, 1] * (np.log10(300.) - np.log10(30.)))
+    P[:, 2] = 0.4
+    P[:, 3] = 0.5 * u[:, 2]
+    P[:, 4] = 0.5 * u[:, 3]
+    P[:, 5] = 3.0 * u[:, 4]
+    return P
+
+
+def bytes_per_eval(fit, itemsize=8):
+    """Algorithmic HBM bytes of one likelihood evaluation:
+    write Iunif; read Iunif + write Iconv; read Iconv + read data."""
+    e = fit.engine
+    return itemsize * e.nv * (4 * e.nneed**2 + e.nx * e.ny)
