@@ -93,13 +93,51 @@ struct WalkerK {
 // ---------------------------------------------------------------------------
 __device__ inline double sgn(double x) { return (x > 0) - (x < 0); }
 
+__device__ inline int find_cell(const double* __restrict__ gr, int n, double q,
+                                double inv_step) {
+  // i with gr[i] <= q < gr[i+1], clipped to [0, n-2] (searchsorted semantics)
+  int i = (int)floor((q - gr[0]) * inv_step);
+  i = min(max(i, 0), n - 2);
+  while (i > 0 && q < gr[i]) --i;
+  while (i < n - 2 && q >= gr[i + 1]) ++i;
+  return i;
+}
+
+// Cell index and fractional position of one observed coordinate on the model
+// axis `gr` (scipy RegularGridInterpolator, linear, bounds_error=False,
+// fill_value=0; :479-481): cell -1 = outside (value 0), -2 = NaN query.
+__device__ inline void regrid_cell(const double* __restrict__ gr, int n, double q,
+                                   int* cell, double* frac) {
+  int c;
+  double t = 0.0;
+  if (q != q) {
+    c = -2;
+  } else if (q < gr[0] || q > gr[n - 1]) {
+    c = -1;
+  } else {
+    c = find_cell(gr, n, q, 1.0 / (gr[1] - gr[0]));
+    t = (q - gr[c]) / (gr[c + 1] - gr[c]);
+  }
+  *cell = c;
+  *frac = t;
+}
+
 __global__ void k_prep(FitK g, const double* __restrict__ params, int nw,
-                       WalkerK* __restrict__ wk) {
+                       WalkerK* __restrict__ wk, int* __restrict__ cellx,
+                       double* __restrict__ fracx, int* __restrict__ celly,
+                       double* __restrict__ fracy) {
   const int w = blockIdx.x;
   if (w >= nw) return;
   const double* p = params + (long long)w * NP;
   WalkerK& o = wk[w];
   const int t = threadIdx.x;
+  // rgi2d's query points X - xoff, Y - yoff (:481), per axis
+  for (int i = t; i < g.nx; i += blockDim.x)
+    regrid_cell(g.xneed, g.nneed, g.xobs[i] - p[8], &cellx[(long long)w * g.nx + i],
+                &fracx[(long long)w * g.nx + i]);
+  for (int j = t; j < g.ny; j += blockDim.x)
+    regrid_cell(g.yneed, g.nneed, g.yobs[j] - p[9], &celly[(long long)w * g.ny + j],
+                &fracy[(long long)w * g.ny + j]);
   const double cs = p[2];
   // update_prof (:412-427)
   const double c = cs / g.dv;
@@ -368,16 +406,40 @@ k_conv_sep(FitK g, const double* __restrict__ in, double* __restrict__ out,
   double* dst = out + (long long)blockIdx.z * plane;
   const int x0 = blockIdx.x * TX, y0 = blockIdx.y * TY;
 
-  // 1. stage the input tile (zero outside the image and in the pad)
-  for (int e = tid; e < rows * P; e += 256) {
-    const int rr = e / P, cc = e - rr * P;
-    const int gy = y0 - ng + rr, gx = x0 - ng + cc;
-    double v = 0.0;
-    if (rr < TY + K - 1 && cc < TX + K - 1 && gy >= 0 && gy < n && gx >= 0 && gx < n)
-      v = src[(long long)gy * n + gx];
-    lds[e] = v;
+  // 1. stage the input tile (zero outside the image and in the pad).  Wave w
+  //    takes rows w, w+4, ...; 8 rows x 1 column chunk = 8 independent loads in
+  //    flight per lane before the first LDS write.
+  const int lane = tid & 63, wv = tid >> 6;
+  const int vrows = TY + K - 1, vcols = TX + K - 1;
+  bool any = false;
+  for (int c0 = 0; c0 < P; c0 += 64) {
+    const int cc = c0 + lane;
+    const int gx = x0 - ng + cc;
+    const bool colok = cc < vcols && gx >= 0 && gx < n;
+    for (int r0 = wv; r0 < rows; r0 += 4 * 8) {
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int rr = r0 + 4 * u;
+        const int gy = y0 - ng + rr;
+        v[u] = (colok && rr < vrows && gy >= 0 && gy < n) ? src[(long long)gy * n + gx] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int rr = r0 + 4 * u;
+        any |= v[u] != 0.0;
+        if (rr < rows && cc < P) lds[rr * P + cc] = v[u];
+      }
+    }
   }
-  __syncthreads();
+  // an all-zero tile (most of a channel map is empty sky) convolves to zero
+  if (!__syncthreads_or(any)) {
+    for (int e = tid; e < TX * TY; e += 256) {
+      const int gy = y0 + e / TX, gxo = x0 + (e & (TX - 1));
+      if (gxo < n && gy < n) dst[(long long)gy * n + gxo] = 0.0;
+    }
+    return;
+  }
 
   // 2. row pass: tmp[row][x] = sum_u gxf[u] * tile[row][x+u]
   const int nitem = rows * (TX / R);
@@ -420,7 +482,7 @@ k_conv_sep(FitK g, const double* __restrict__ in, double* __restrict__ out,
 
   // 3. column pass: out[y][x] = sum_u gyf[u] * tmp[y+u][x]; lanes <-> x
   const double* wy = g.gy_pad;
-  const int lane_x = tid & (TX - 1);
+  const int lane_x = lane;
   for (int yb = tid / TX; yb < TY / R; yb += 256 / TX) {
     const double* col = lds + (yb * R) * P2 + lane_x;
     double acc[R], win[R];
@@ -518,58 +580,44 @@ k_peak_unity(FitK g, const double* __restrict__ in, double* __restrict__ out) {
 // get_scale (:485-490).  Wave shuffle reduction, then a block reduction; the
 // per-block partials are summed in fixed order by k_finalize.
 // ---------------------------------------------------------------------------
-__device__ inline int find_cell(const double* __restrict__ gr, int n, double q,
-                                double inv_step) {
-  // i with gr[i] <= q < gr[i+1], clipped to [0, n-2] (searchsorted semantics)
-  int i = (int)floor((q - gr[0]) * inv_step);
-  i = min(max(i, 0), n - 2);
-  while (i > 0 && q < gr[i]) --i;
-  while (i < n - 2 && q >= gr[i + 1]) ++i;
-  return i;
-}
-
 __device__ inline double wave_sum(double v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
   return v;
 }
 
+constexpr int RG_ROWS = 16;   // observed rows per block
+
 template <bool WRITE>
 __global__ void __launch_bounds__(RED_THREADS)
-k_regrid(FitK g, const WalkerK* __restrict__ wk, const double* __restrict__ iconv,
-         double* __restrict__ partial, double* __restrict__ cube_out) {
-  const int wi = blockIdx.z;
-  const WalkerK& w = wk[wi];
+k_regrid(FitK g, const int* __restrict__ cellx, const double* __restrict__ fracx,
+         const int* __restrict__ celly, const double* __restrict__ fracy,
+         const double* __restrict__ iconv, double* __restrict__ partial,
+         double* __restrict__ cube_out) {
+  const int wi = blockIdx.z / g.nv, k = blockIdx.z - wi * g.nv;
   const int n = g.nneed;
-  const long long nobs = (long long)g.ny * g.nx;
-  const long long total = nobs * g.nv;
-  const double* src = iconv + (long long)wi * g.nv * n * n;
-  const double inv_sx = 1.0 / (g.xneed[1] - g.xneed[0]);
-  const double inv_sy = 1.0 / (g.yneed[1] - g.yneed[0]);
+  const int ix = blockIdx.x * RED_THREADS + threadIdx.x;
+  const bool live = ix < g.nx;
+  const int i1 = live ? cellx[(long long)wi * g.nx + ix] : -1;
+  const double t1 = live ? fracx[(long long)wi * g.nx + ix] : 0.0;
+  const double* src = iconv + ((long long)wi * g.nv + k) * n * n;
+  const long long obase = (long long)k * g.ny * g.nx;
+  const int j0 = blockIdx.y * RG_ROWS, j1 = min(g.ny, j0 + RG_ROWS);
   double gf = 0.0, ff = 0.0;
-  for (long long e = (long long)blockIdx.x * RED_THREADS + threadIdx.x; e < total;
-       e += (long long)gridDim.x * RED_THREADS) {
-    const int k = (int)(e / nobs);
-    const int rem = (int)(e - (long long)k * nobs);
-    const int jy = rem / g.nx, ix = rem - jy * g.nx;
-    const double qx = g.xobs[ix] - w.xoff;                 // :481
-    const double qy = g.yobs[jy] - w.yoff;
-    double val;
-    if (qx != qx || qy != qy) {
+  for (int jy = j0; jy < j1; ++jy) {
+    const int i0 = celly[(long long)wi * g.ny + jy];      // wave-uniform
+    const double t0 = fracy[(long long)wi * g.ny + jy];
+    if (!live) continue;
+    double val = 0.0;                                     // fill_value=0 outside
+    if (i0 == -2 || i1 == -2) {
       val = __builtin_nan("");
-    } else if (qx < g.xneed[0] || qx > g.xneed[n - 1] || qy < g.yneed[0] ||
-               qy > g.yneed[n - 1]) {
-      val = 0.0;                                           // fill_value=0
-    } else {
-      const int i1 = find_cell(g.xneed, n, qx, inv_sx);
-      const int i0 = find_cell(g.yneed, n, qy, inv_sy);
-      const double t1 = (qx - g.xneed[i1]) / (g.xneed[i1 + 1] - g.xneed[i1]);
-      const double t0 = (qy - g.yneed[i0]) / (g.yneed[i0 + 1] - g.yneed[i0]);
-      const double* c = src + ((long long)k * n + i0) * n + i1;
+    } else if (i0 >= 0 && i1 >= 0) {
+      const double* c = src + (long long)i0 * n + i1;
       const double v00 = c[0], v01 = c[1], v10 = c[n], v11 = c[n + 1];
       val = v00 * (1 - t0) * (1 - t1) + v01 * (1 - t0) * t1 +
             v10 * t0 * (1 - t1) + v11 * t0 * t1;
     }
+    const long long e = obase + (long long)jy * g.nx + ix;
     if (WRITE) cube_out[e] = val;
     gf = fma(val, g.data[e], gf);
     ff = fma(val, val, ff);
@@ -583,9 +631,9 @@ k_regrid(FitK g, const WalkerK* __restrict__ wk, const double* __restrict__ icon
   if (threadIdx.x == 0) {
     double a = 0.0, b = 0.0;
     for (int q = 0; q < RED_THREADS / 64; ++q) { a += sg[q]; b += sf[q]; }
-    double* p = partial + ((long long)wi * gridDim.x + blockIdx.x) * 2;
-    p[0] = a;
-    p[1] = b;
+    const long long blk = ((long long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    partial[2 * blk] = a;
+    partial[2 * blk + 1] = b;
   }
 }
 
@@ -651,7 +699,12 @@ struct slamhip_ctx {
   double* d_partial = nullptr;
   double* d_stats = nullptr;
   double* d_chi2 = nullptr;
-  int red_blocks = 0;
+  int* d_cellx = nullptr;
+  int* d_celly = nullptr;
+  double* d_fracx = nullptr;
+  double* d_fracy = nullptr;
+  int red_blocks = 0;      // k_regrid partials per walker
+  dim3 rg_grid{1, 1, 1};   // k_regrid grid for ONE walker (z = nv)
   int separable = 0;
   int conv_mode = 0;
   int kpad = 0;
@@ -802,7 +855,8 @@ int run_model(slamhip_ctx* c, const double* d_params, int nw, hipStream_t st) {
   const FitK& k = c->k;
   {
     Timed t_(c, KID_PREP, st);
-    hipLaunchKernelGGL(k_prep, dim3(nw), dim3(64), 0, st, k, d_params, nw, c->d_wk);
+    hipLaunchKernelGGL(k_prep, dim3(nw), dim3(64), 0, st, k, d_params, nw, c->d_wk,
+                       c->d_cellx, c->d_fracx, c->d_celly, c->d_fracy);
   }
   {
     Timed t_(c, KID_SURFACE, st);
@@ -827,9 +881,10 @@ int run_group(slamhip_ctx* c, const double* d_params, int nw, double* d_chi2,
   if (rc) return rc;
   {
     Timed t_(c, KID_REGRID, st);
-    dim3 g4(c->red_blocks, 1, nw);
-    hipLaunchKernelGGL((k_regrid<false>), g4, dim3(RED_THREADS), 0, st, c->k, c->d_wk,
-                       c->d_iconv, c->d_partial, (double*)nullptr);
+    dim3 g4(c->rg_grid.x, c->rg_grid.y, c->rg_grid.z * nw);
+    hipLaunchKernelGGL((k_regrid<false>), g4, dim3(RED_THREADS), 0, st, c->k, c->d_cellx,
+                       c->d_fracx, c->d_celly, c->d_fracy, c->d_iconv, c->d_partial,
+                       (double*)nullptr);
   }
   {
     Timed t_(c, KID_FINALIZE, st);
@@ -941,17 +996,15 @@ int slamhip_create(const slamhip_desc* d, slamhip_ctx** out) {
     c->sep_variant = 2; c->sep_lds = sep_lds_bytes(32, c->kpad);
   }
   c->c2d_lds = (size_t)(C2_TY + K - 1) * ((C2_TX + K - 1) | 1) * sizeof(double);
-  if (c->sep_lds > 64 * 1024) {
-    HIP_TRY(c, hipFuncSetAttribute((const void*)k_conv_sep<64, 5>,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIP_TRY(c, hipFuncSetAttribute((const void*)k_conv_sep<64, 3>,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIP_TRY(c, hipFuncSetAttribute((const void*)k_conv_sep<32, 4>,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  if (c->sep_lds > 48 * 1024) {   // opt in to large dynamic LDS for the chosen variant only
+    const void* fn = c->sep_variant == 0 ? (const void*)k_conv_sep<64, 3>
+                   : c->sep_variant == 1 ? (const void*)k_conv_sep<64, 5>
+                                         : (const void*)k_conv_sep<32, 4>;
+    HIP_TRY(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->sep_lds));
   }
-  if (c->c2d_lds > 64 * 1024)
+  if (c->c2d_lds > 48 * 1024 && c->c2d_lds <= 160 * 1024)
     HIP_TRY(c, hipFuncSetAttribute((const void*)k_conv_2d,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->c2d_lds));
 
   // --- uploads -------------------------------------------------------------
   int rc;
@@ -980,7 +1033,8 @@ int slamhip_create(const slamhip_desc* d, slamhip_ctx** out) {
   c->wgroup = (int)std::max<size_t>(1, std::min<size_t>(32, budget / per_walker));
   // keep conv's grid.z within limits
   while (c->wgroup > 1 && (long long)c->wgroup * k.nv > 32768) --c->wgroup;
-  c->red_blocks = (int)std::min<long long>(2048, ((long long)ncube + RED_THREADS - 1) / RED_THREADS);
+  c->rg_grid = dim3((k.nx + RED_THREADS - 1) / RED_THREADS, (k.ny + RG_ROWS - 1) / RG_ROWS, k.nv);
+  c->red_blocks = (int)(c->rg_grid.x * c->rg_grid.y * c->rg_grid.z);
   const size_t W = c->wgroup;
   if ((rc = dev_alloc(c, &c->d_wk, W))) return rc;
   if ((rc = dev_alloc(c, &c->d_params, W * NP))) return rc;
@@ -991,6 +1045,10 @@ int slamhip_create(const slamhip_desc* d, slamhip_ctx** out) {
   if ((rc = dev_alloc(c, &c->d_partial, W * c->red_blocks * 2))) return rc;
   if ((rc = dev_alloc(c, &c->d_stats, W * 4))) return rc;
   if ((rc = dev_alloc(c, &c->d_chi2, W))) return rc;
+  if ((rc = dev_alloc(c, &c->d_cellx, W * k.nx))) return rc;
+  if ((rc = dev_alloc(c, &c->d_fracx, W * k.nx))) return rc;
+  if ((rc = dev_alloc(c, &c->d_celly, W * k.ny))) return rc;
+  if ((rc = dev_alloc(c, &c->d_fracy, W * k.ny))) return rc;
   HIP_TRY(c, hipStreamCreate(&c->stream));
   HIP_TRY(c, hipDeviceSynchronize());
   return SLAMHIP_OK;
@@ -1133,8 +1191,9 @@ int slamhip_cubemodel(slamhip_ctx* c, const double* params, int convolving,
   const size_t ncube = (size_t)k.nv * k.ny * k.nx;
   double* d_cube = nullptr;
   HIP_TRY(c, hipMalloc((void**)&d_cube, ncube * sizeof(double)));
-  hipLaunchKernelGGL((k_regrid<true>), dim3(c->red_blocks, 1, 1), dim3(RED_THREADS), 0, c->stream,
-                     k, c->d_wk, c->d_iconv, c->d_partial, d_cube);
+  hipLaunchKernelGGL((k_regrid<true>), c->rg_grid, dim3(RED_THREADS), 0, c->stream, k,
+                     c->d_cellx, c->d_fracx, c->d_celly, c->d_fracy, c->d_iconv, c->d_partial,
+                     d_cube);
   hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, c->stream, k, c->d_partial, c->red_blocks,
                      c->d_stats, (double*)nullptr);
   hipLaunchKernelGGL(k_scale, dim3(1024), dim3(256), 0, c->stream, d_cube, (long long)ncube, c->d_stats);
@@ -1155,7 +1214,8 @@ int slamhip_surface(slamhip_ctx* c, const double* params, int slot, double* x_ou
   if (rc) return rc;
   if (slot < 0 || slot > 3 || !x_out || !v_out) return fail(c, SLAMHIP_ERR_ARG, "surface: bad arguments");
   const FitK& k = c->k;
-  hipLaunchKernelGGL(k_prep, dim3(1), dim3(64), 0, c->stream, k, c->d_params, 1, c->d_wk);
+  hipLaunchKernelGGL(k_prep, dim3(1), dim3(64), 0, c->stream, k, c->d_params, 1, c->d_wk,
+                     c->d_cellx, c->d_fracx, c->d_celly, c->d_fracy);
   WalkerK hw;
   HIP_TRY(c, hipMemcpyAsync(&hw, c->d_wk, sizeof hw, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -1180,7 +1240,8 @@ int slamhip_prof(slamhip_ctx* c, double cs, double* prof_out, double* prof_d_out
   double p[NP] = {1, 1, cs, 0, -1, 0, 0, 0, 0, 0, 0, 0, 0};
   int rc = single_prepare(c, p);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_prep, dim3(1), dim3(64), 0, c->stream, c->k, c->d_params, 1, c->d_wk);
+  hipLaunchKernelGGL(k_prep, dim3(1), dim3(64), 0, c->stream, c->k, c->d_params, 1, c->d_wk,
+                     c->d_cellx, c->d_fracx, c->d_celly, c->d_fracy);
   WalkerK hw;
   HIP_TRY(c, hipMemcpyAsync(&hw, c->d_wk, sizeof hw, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
