@@ -91,6 +91,12 @@ int slamhip_chi2_batch(slamhip_ctx* ctx, const double* params, int nw,
 int slamhip_chi2_batch_dev(slamhip_ctx* ctx, const double* params_dev, int nw,
                            double* chi2_dev, void* stream);
 
+/* Hot path with its intermediate sums exposed (parity tap for get_scale,
+ * :485-490): per walker {gf, ff, scale, chi2, non-empty tiles, tiles}.
+ * `params` [nw][13], `stats_out` [nw][6] are host pointers. Synchronous. */
+int slamhip_chi2_stats(slamhip_ctx* ctx, const double* params, int nw,
+                       double* stats_out);
+
 /* Replaces `ChannelFit.cubemodel(*p, convolving)` (:499-537): writes the
  * scaled model cube [nv][ny][nx] to the host buffer `out`.
  * `stats_out` (may be NULL) receives {gf, ff, scale, chi2} (:485-490, :601). */

@@ -125,7 +125,8 @@ __device__ inline void regrid_cell(const double* __restrict__ gr, int n, double 
 __global__ void k_prep(FitK g, const double* __restrict__ params, int nw,
                        WalkerK* __restrict__ wk, int* __restrict__ cellx,
                        double* __restrict__ fracx, int* __restrict__ celly,
-                       double* __restrict__ fracy) {
+                       double* __restrict__ fracy, int* __restrict__ tile_ix,
+                       int* __restrict__ tile_jy, int ntx, int nty, int sx, int sy) {
   const int w = blockIdx.x;
   if (w >= nw) return;
   const double* p = params + (long long)w * NP;
@@ -138,6 +139,22 @@ __global__ void k_prep(FitK g, const double* __restrict__ params, int nw,
   for (int j = t; j < g.ny; j += blockDim.x)
     regrid_cell(g.yneed, g.nneed, g.yobs[j] - p[9], &celly[(long long)w * g.ny + j],
                 &fracy[(long long)w * g.ny + j]);
+  // observed index range [lo, hi) whose cells fall in each conv tile's span
+  __syncthreads();
+  for (int tl = t; tl < ntx + nty; tl += blockDim.x) {
+    const bool isx = tl < ntx;
+    const int tt = isx ? tl : tl - ntx;
+    const int c0 = tt * (isx ? sx : sy), c1 = c0 + (isx ? sx : sy);
+    const int* cell = isx ? &cellx[(long long)w * g.nx] : &celly[(long long)w * g.ny];
+    const int m = isx ? g.nx : g.ny;
+    int lo = m, hi = 0;
+    for (int i = 0; i < m; ++i)
+      if (cell[i] >= c0 && cell[i] < c1) { lo = min(lo, i); hi = max(hi, i + 1); }
+    if (hi == 0) lo = 0;
+    int* o2 = isx ? &tile_ix[((long long)w * ntx + tt) * 2] : &tile_jy[((long long)w * nty + tt) * 2];
+    o2[0] = lo;
+    o2[1] = hi;
+  }
   const double cs = p[2];
   // update_prof (:412-427)
   const double c = cs / g.dv;
@@ -389,11 +406,27 @@ k_profile(FitK g, const WalkerK* __restrict__ wk,
 // LDS buffer serves as input tile and as the intermediate.  Each thread slides
 // a CONV_R-wide register window along the tap axis: 1 LDS read per CONV_R FMAs.
 // ---------------------------------------------------------------------------
+__device__ inline double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+template <int TY>
+struct ConvAcc {
+  static constexpr int NYB = (TY / CONV_R) / (256 / CONV_TX);   // y-blocks per thread
+  double v[NYB][CONV_R];
+};
+
+// Convolves the TX x TY output nodes whose corner is (x0, y0) with the
+// separable beam.  On return thread (lane, wave) holds, for q < NYB, rows
+// (wave + 4q)*R .. +R-1 of column `lane`.  Returns false (nothing computed)
+// when the staged input tile is all zero.  Leaves the block past a barrier:
+// LDS may be reused after one more __syncthreads().
 template <int TY, int MAXR>
-__global__ void __launch_bounds__(256)
-k_conv_sep(FitK g, const double* __restrict__ in, double* __restrict__ out,
-           int kpad) {
-  extern __shared__ double lds[];
+__device__ inline bool conv_tile(const FitK& g, const double* __restrict__ src,
+                                 int x0, int y0, int kpad, double* lds,
+                                 ConvAcc<TY>& acc) {
   constexpr int TX = CONV_TX, R = CONV_R;
   const int K = g.kbeam, ng = g.ngauss, n = g.nneed;
   const int rows = TY + kpad - 1;              // tile rows incl. halo + zero pad
@@ -401,14 +434,10 @@ k_conv_sep(FitK g, const double* __restrict__ in, double* __restrict__ out,
   const int P = cols | 1;                      // odd pitch: lanes<->rows conflict-free
   const int P2 = TX + 1;
   const int tid = threadIdx.x;
-  const long long plane = (long long)n * n;
-  const double* src = in + (long long)blockIdx.z * plane;
-  double* dst = out + (long long)blockIdx.z * plane;
-  const int x0 = blockIdx.x * TX, y0 = blockIdx.y * TY;
 
   // 1. stage the input tile (zero outside the image and in the pad).  Wave w
-  //    takes rows w, w+4, ...; 8 rows x 1 column chunk = 8 independent loads in
-  //    flight per lane before the first LDS write.
+  //    takes rows w, w+4, ...; 8 independent loads in flight per lane before
+  //    the first LDS write.
   const int lane = tid & 63, wv = tid >> 6;
   const int vrows = TY + K - 1, vcols = TX + K - 1;
   bool any = false;
@@ -433,13 +462,7 @@ k_conv_sep(FitK g, const double* __restrict__ in, double* __restrict__ out,
     }
   }
   // an all-zero tile (most of a channel map is empty sky) convolves to zero
-  if (!__syncthreads_or(any)) {
-    for (int e = tid; e < TX * TY; e += 256) {
-      const int gy = y0 + e / TX, gxo = x0 + (e & (TX - 1));
-      if (gxo < n && gy < n) dst[(long long)gy * n + gxo] = 0.0;
-    }
-    return;
-  }
+  if (!__syncthreads_or(any)) return false;
 
   // 2. row pass: tmp[row][x] = sum_u gxf[u] * tile[row][x+u]
   const int nitem = rows * (TX / R);
@@ -482,12 +505,13 @@ k_conv_sep(FitK g, const double* __restrict__ in, double* __restrict__ out,
 
   // 3. column pass: out[y][x] = sum_u gyf[u] * tmp[y+u][x]; lanes <-> x
   const double* wy = g.gy_pad;
-  const int lane_x = lane;
-  for (int yb = tid / TX; yb < TY / R; yb += 256 / TX) {
-    const double* col = lds + (yb * R) * P2 + lane_x;
-    double acc[R], win[R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) acc[r] = 0.0;
+  for (int q = 0; q < ConvAcc<TY>::NYB; ++q) {
+    const int yb = wv + 4 * q;
+    const double* col = lds + (yb * R) * P2 + lane;
+    double win[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc.v[q][r] = 0.0;
 #pragma unroll
     for (int r = 0; r < R - 1; ++r) win[r] = col[r * P2];
     for (int u0 = 0; u0 < kpad; u0 += R) {
@@ -497,15 +521,111 @@ k_conv_sep(FitK g, const double* __restrict__ in, double* __restrict__ out,
         const double wgt = wy[u0 + qq];
 #pragma unroll
         for (int r = 0; r < R; ++r)
-          acc[r] = fma(wgt, win[(r + qq) % R], acc[r]);
+          acc.v[q][r] = fma(wgt, win[(r + qq) % R], acc.v[q][r]);
       }
     }
-    const int gx = x0 + lane_x;
+  }
+  return true;
+}
+
+// k_conv_sep: convolved cube to HBM (cubemodel / parity tap path).
+template <int TY, int MAXR>
+__global__ void __launch_bounds__(256)
+k_conv_sep(FitK g, const double* __restrict__ in, double* __restrict__ out,
+           int kpad) {
+  extern __shared__ double lds[];
+  constexpr int TX = CONV_TX, R = CONV_R;
+  const int n = g.nneed;
+  const long long plane = (long long)n * n;
+  const double* src = in + (long long)blockIdx.z * plane;
+  double* dst = out + (long long)blockIdx.z * plane;
+  const int x0 = blockIdx.x * TX, y0 = blockIdx.y * TY;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  ConvAcc<TY> acc;
+  if (!conv_tile<TY, MAXR>(g, src, x0, y0, kpad, lds, acc)) {
+    for (int e = tid; e < TX * TY; e += 256) {
+      const int gy = y0 + e / TX, gxo = x0 + (e & (TX - 1));
+      if (gxo < n && gy < n) dst[(long long)gy * n + gxo] = 0.0;
+    }
+    return;
+  }
+  const int gx = x0 + lane;
+#pragma unroll
+  for (int q = 0; q < ConvAcc<TY>::NYB; ++q)
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      const int gy = y0 + yb * R + r;
-      if (gx < n && gy < n) dst[(long long)gy * n + gx] = acc[r];
+      const int gy = y0 + (wv + 4 * q) * R + r;
+      if (gx < n && gy < n) dst[(long long)gy * n + gx] = acc.v[q][r];
     }
+}
+
+// k_conv_chi2: the hot-path form.  Convolves a tile, keeps it in LDS, regrids
+// it bilinearly onto the observed pixels whose interpolation cell it owns
+// (:475-483) and reduces sum(I*d), sum(I*I) for get_scale (:485-490): wave
+// shuffles, then a block reduction.  The convolved cube never reaches HBM, and
+// an all-zero tile costs neither FLOPs nor a read of the data cube.
+// Tiles overlap by one node: tile (bx, by) owns cells [x0, x0+TX-1) x
+// [y0, y0+TY-1) with x0 = bx*(TX-1), y0 = by*(TY-1).
+template <int TY, int MAXR>
+__global__ void __launch_bounds__(256)
+k_conv_chi2(FitK g, const double* __restrict__ iunif,
+            const int* __restrict__ cellx, const double* __restrict__ fracx,
+            const int* __restrict__ celly, const double* __restrict__ fracy,
+            const int* __restrict__ tile_ix, const int* __restrict__ tile_jy,
+            double* __restrict__ partial, int kpad) {
+  extern __shared__ double lds[];
+  constexpr int TX = CONV_TX, R = CONV_R, PC = TX + 1;
+  const int n = g.nneed;
+  const int wi = blockIdx.z / g.nv, k = blockIdx.z - wi * g.nv;
+  const double* src = iunif + (long long)blockIdx.z * n * n;
+  const int x0 = blockIdx.x * (TX - 1), y0 = blockIdx.y * (TY - 1);
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const long long blk = ((long long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+  ConvAcc<TY> acc;
+  if (!conv_tile<TY, MAXR>(g, src, x0, y0, kpad, lds, acc)) {
+    if (tid == 0) { partial[3 * blk] = 0.0; partial[3 * blk + 1] = 0.0; partial[3 * blk + 2] = 0.0; }
+    return;
+  }
+  __syncthreads();                         // column pass done reading LDS
+#pragma unroll
+  for (int q = 0; q < ConvAcc<TY>::NYB; ++q)
+#pragma unroll
+    for (int r = 0; r < R; ++r) lds[((wv + 4 * q) * R + r) * PC + lane] = acc.v[q][r];
+  __syncthreads();
+  const int* tix = tile_ix + ((long long)wi * gridDim.x + blockIdx.x) * 2;
+  const int* tjy = tile_jy + ((long long)wi * gridDim.y + blockIdx.y) * 2;
+  const int ixa = tix[0], ixb = tix[1], jya = tjy[0], jyb = tjy[1];
+  const int* cx = cellx + (long long)wi * g.nx;
+  const int* cy = celly + (long long)wi * g.ny;
+  const double* fx = fracx + (long long)wi * g.nx;
+  const double* fy = fracy + (long long)wi * g.ny;
+  const double* dat = g.data + (long long)k * g.ny * g.nx;
+  double gf = 0.0, ff = 0.0;
+  for (int ix = ixa + lane; ix < ixb; ix += 64) {
+    const int i1 = cx[ix] - x0;
+    const double t1 = fx[ix];
+    if (i1 < 0 || i1 >= TX - 1) continue;                  // owned by another tile
+    for (int jy = jya + wv; jy < jyb; jy += 4) {
+      const int i0 = cy[jy] - y0;                          // wave-uniform
+      if (i0 < 0 || i0 >= TY - 1) continue;
+      const double t0 = fy[jy];
+      const double* c = lds + i0 * PC + i1;
+      const double v00 = c[0], v01 = c[1], v10 = c[PC], v11 = c[PC + 1];
+      const double val = v00 * (1 - t0) * (1 - t1) + v01 * (1 - t0) * t1 +
+                         v10 * t0 * (1 - t1) + v11 * t0 * t1;
+      gf = fma(val, dat[(long long)jy * g.nx + ix], gf);
+      ff = fma(val, val, ff);
+    }
+  }
+  __shared__ double sg[4], sf[4];
+  gf = wave_sum(gf);
+  ff = wave_sum(ff);
+  if (lane == 0) { sg[wv] = gf; sf[wv] = ff; }
+  __syncthreads();
+  if (tid == 0) {
+    partial[3 * blk] = (sg[0] + sg[1]) + (sg[2] + sg[3]);
+    partial[3 * blk + 1] = (sf[0] + sf[1]) + (sf[2] + sf[3]);
+    partial[3 * blk + 2] = 1.0;                            // tile was not empty
   }
 }
 
@@ -580,12 +700,6 @@ k_peak_unity(FitK g, const double* __restrict__ in, double* __restrict__ out) {
 // get_scale (:485-490).  Wave shuffle reduction, then a block reduction; the
 // per-block partials are summed in fixed order by k_finalize.
 // ---------------------------------------------------------------------------
-__device__ inline double wave_sum(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-  return v;
-}
-
 constexpr int RG_ROWS = 16;   // observed rows per block
 
 template <bool WRITE>
@@ -632,8 +746,9 @@ k_regrid(FitK g, const int* __restrict__ cellx, const double* __restrict__ fracx
     double a = 0.0, b = 0.0;
     for (int q = 0; q < RED_THREADS / 64; ++q) { a += sg[q]; b += sf[q]; }
     const long long blk = ((long long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-    partial[2 * blk] = a;
-    partial[2 * blk + 1] = b;
+    partial[3 * blk] = a;
+    partial[3 * blk + 1] = b;
+    partial[3 * blk + 2] = 1.0;
   }
 }
 
@@ -641,16 +756,19 @@ k_regrid(FitK g, const int* __restrict__ cellx, const double* __restrict__ fracx
 //   scale = gf/ff, 0 if ff == 0 or scale < 0                        (:488-489)
 //   chi2  = sum((d - scale*I)^2)/sigma^2/pixperbeam                 (:601-602)
 //         = (sum d^2 - 2 s gf + s^2 ff)/sigma^2/pixperbeam
-// stats[w] = {gf, ff, scale, chi2}
+// stats[w] = {gf, ff, scale, chi2, non-empty blocks, blocks}
 __global__ void __launch_bounds__(64)
 k_finalize(FitK g, const double* __restrict__ partial, int nblk,
            double* __restrict__ stats, double* __restrict__ chi2_out) {
   const int wi = blockIdx.x;
-  const double* p = partial + (long long)wi * nblk * 2;
-  double a = 0.0, b = 0.0;
-  for (int q = threadIdx.x; q < nblk; q += 64) { a += p[2 * q]; b += p[2 * q + 1]; }
+  const double* p = partial + (long long)wi * nblk * 3;
+  double a = 0.0, b = 0.0, live = 0.0;
+  for (int q = threadIdx.x; q < nblk; q += 64) {
+    a += p[3 * q]; b += p[3 * q + 1]; live += p[3 * q + 2];
+  }
   a = wave_sum(a);
   b = wave_sum(b);
+  live = wave_sum(live);
   if (threadIdx.x == 0) {
     double s = a / b;
     if (b == 0.0 || s < 0.0) s = 0.0;
@@ -663,8 +781,9 @@ k_finalize(FitK g, const double* __restrict__ partial, int nblk,
       c2 = (g.ssq_data - 2.0 * s * a + s * s * b) / (g.sigma * g.sigma) / g.pixperbeam;
     }
     if (stats) {
-      stats[4 * wi + 0] = a; stats[4 * wi + 1] = b;
-      stats[4 * wi + 2] = s; stats[4 * wi + 3] = c2;
+      stats[6 * wi + 0] = a; stats[6 * wi + 1] = b;
+      stats[6 * wi + 2] = s; stats[6 * wi + 3] = c2;
+      stats[6 * wi + 4] = live; stats[6 * wi + 5] = (double)nblk;
     }
     if (chi2_out) chi2_out[wi] = c2;
   }
@@ -703,6 +822,11 @@ struct slamhip_ctx {
   int* d_celly = nullptr;
   double* d_fracx = nullptr;
   double* d_fracy = nullptr;
+  int* d_tile_ix = nullptr;
+  int* d_tile_jy = nullptr;
+  int fused = 0;           // hot path uses k_conv_chi2
+  dim3 fz_grid{1, 1, 1};   // k_conv_chi2 grid for ONE walker (z = nv)
+  int fz_sx = 1, fz_sy = 1;
   int red_blocks = 0;      // k_regrid partials per walker
   dim3 rg_grid{1, 1, 1};   // k_regrid grid for ONE walker (z = nv)
   int separable = 0;
@@ -856,7 +980,8 @@ int run_model(slamhip_ctx* c, const double* d_params, int nw, hipStream_t st) {
   {
     Timed t_(c, KID_PREP, st);
     hipLaunchKernelGGL(k_prep, dim3(nw), dim3(64), 0, st, k, d_params, nw, c->d_wk,
-                       c->d_cellx, c->d_fracx, c->d_celly, c->d_fracy);
+                       c->d_cellx, c->d_fracx, c->d_celly, c->d_fracy, c->d_tile_ix,
+                       c->d_tile_jy, (int)c->fz_grid.x, (int)c->fz_grid.y, c->fz_sx, c->fz_sy);
   }
   {
     Timed t_(c, KID_SURFACE, st);
@@ -877,6 +1002,31 @@ int run_group(slamhip_ctx* c, const double* d_params, int nw, double* d_chi2,
               hipStream_t st) {
   int rc = run_model(c, d_params, nw, st);
   if (rc) return rc;
+  if (c->fused && c->conv_mode == 0) {
+    {
+      Timed t_(c, KID_CONV, st);
+      dim3 gz(c->fz_grid.x, c->fz_grid.y, c->fz_grid.z * nw);
+      const int nblk = (int)(c->fz_grid.x * c->fz_grid.y * c->fz_grid.z);
+      (void)nblk;
+#define SLAM_FUSED(TY_, MR_)                                                              \
+      hipLaunchKernelGGL((k_conv_chi2<TY_, MR_>), gz, dim3(256), c->sep_lds, st, c->k,    \
+                         c->d_iunif, c->d_cellx, c->d_fracx, c->d_celly, c->d_fracy,       \
+                         c->d_tile_ix, c->d_tile_jy, c->d_partial, c->kpad)
+      switch (c->sep_variant) {
+        case 0: SLAM_FUSED(64, 3); break;
+        case 1: SLAM_FUSED(64, 5); break;
+        default: SLAM_FUSED(32, 4); break;
+      }
+#undef SLAM_FUSED
+    }
+    {
+      Timed t_(c, KID_FINALIZE, st);
+      hipLaunchKernelGGL(k_finalize, dim3(nw), dim3(64), 0, st, c->k, c->d_partial,
+                         (int)(c->fz_grid.x * c->fz_grid.y * c->fz_grid.z), c->d_stats, d_chi2);
+    }
+    HIP_TRY(c, hipGetLastError());
+    return SLAMHIP_OK;
+  }
   rc = run_conv(c, c->d_iunif, c->d_iconv, nw * c->k.nv, st);
   if (rc) return rc;
   {
@@ -1000,7 +1150,18 @@ int slamhip_create(const slamhip_desc* d, slamhip_ctx** out) {
     const void* fn = c->sep_variant == 0 ? (const void*)k_conv_sep<64, 3>
                    : c->sep_variant == 1 ? (const void*)k_conv_sep<64, 5>
                                          : (const void*)k_conv_sep<32, 4>;
+    const void* fz = c->sep_variant == 0 ? (const void*)k_conv_chi2<64, 3>
+                   : c->sep_variant == 1 ? (const void*)k_conv_chi2<64, 5>
+                                         : (const void*)k_conv_chi2<32, 4>;
     HIP_TRY(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->sep_lds));
+    HIP_TRY(c, hipFuncSetAttribute(fz, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->sep_lds));
+  }
+  c->fused = c->separable && c->sep_variant >= 0;
+  {
+    const int ty = c->sep_variant == 2 ? 32 : 64;
+    c->fz_sx = CONV_TX - 1;
+    c->fz_sy = ty - 1;
+    c->fz_grid = dim3((n - 1 + c->fz_sx - 1) / c->fz_sx, (n - 1 + c->fz_sy - 1) / c->fz_sy, k.nv);
   }
   if (c->c2d_lds > 48 * 1024 && c->c2d_lds <= 160 * 1024)
     HIP_TRY(c, hipFuncSetAttribute((const void*)k_conv_2d,
@@ -1035,6 +1196,7 @@ int slamhip_create(const slamhip_desc* d, slamhip_ctx** out) {
   while (c->wgroup > 1 && (long long)c->wgroup * k.nv > 32768) --c->wgroup;
   c->rg_grid = dim3((k.nx + RED_THREADS - 1) / RED_THREADS, (k.ny + RG_ROWS - 1) / RG_ROWS, k.nv);
   c->red_blocks = (int)(c->rg_grid.x * c->rg_grid.y * c->rg_grid.z);
+  const size_t max_blocks = std::max<size_t>(c->red_blocks, (size_t)c->fz_grid.x * c->fz_grid.y * c->fz_grid.z);
   const size_t W = c->wgroup;
   if ((rc = dev_alloc(c, &c->d_wk, W))) return rc;
   if ((rc = dev_alloc(c, &c->d_params, W * NP))) return rc;
@@ -1042,13 +1204,15 @@ int slamhip_create(const slamhip_desc* d, slamhip_ctx** out) {
   if ((rc = dev_alloc(c, &c->d_wt, W * 4 * k.nleaf))) return rc;
   if ((rc = dev_alloc(c, &c->d_iunif, W * k.nv * n * n))) return rc;
   if ((rc = dev_alloc(c, &c->d_iconv, W * k.nv * n * n))) return rc;
-  if ((rc = dev_alloc(c, &c->d_partial, W * c->red_blocks * 2))) return rc;
-  if ((rc = dev_alloc(c, &c->d_stats, W * 4))) return rc;
+  if ((rc = dev_alloc(c, &c->d_partial, W * max_blocks * 3))) return rc;
+  if ((rc = dev_alloc(c, &c->d_stats, W * 6))) return rc;
   if ((rc = dev_alloc(c, &c->d_chi2, W))) return rc;
   if ((rc = dev_alloc(c, &c->d_cellx, W * k.nx))) return rc;
   if ((rc = dev_alloc(c, &c->d_fracx, W * k.nx))) return rc;
   if ((rc = dev_alloc(c, &c->d_celly, W * k.ny))) return rc;
   if ((rc = dev_alloc(c, &c->d_fracy, W * k.ny))) return rc;
+  if ((rc = dev_alloc(c, &c->d_tile_ix, W * c->fz_grid.x * 2))) return rc;
+  if ((rc = dev_alloc(c, &c->d_tile_jy, W * c->fz_grid.y * 2))) return rc;
   HIP_TRY(c, hipStreamCreate(&c->stream));
   HIP_TRY(c, hipDeviceSynchronize());
   return SLAMHIP_OK;
@@ -1147,6 +1311,24 @@ int slamhip_chi2_batch(slamhip_ctx* c, const double* params, int nw, double* chi
   return SLAMHIP_OK;
 }
 
+int slamhip_chi2_stats(slamhip_ctx* c, const double* params, int nw, double* stats_out) {
+  if (!c || c->wgroup < 1) return SLAMHIP_ERR_STATE;
+  if (nw < 0 || (nw > 0 && (!params || !stats_out)))
+    return fail(c, SLAMHIP_ERR_ARG, "chi2_stats: bad arguments");
+  HIP_TRY(c, hipSetDevice(c->device));
+  for (int w0 = 0; w0 < nw; w0 += c->wgroup) {
+    const int m = std::min(c->wgroup, nw - w0);
+    HIP_TRY(c, hipMemcpyAsync(c->d_params, params + (size_t)w0 * NP, (size_t)m * NP * sizeof(double),
+                              hipMemcpyHostToDevice, c->stream));
+    int rc = run_group(c, c->d_params, m, c->d_chi2, c->stream);
+    if (rc) return rc;
+    HIP_TRY(c, hipMemcpyAsync(stats_out + (size_t)w0 * 6, c->d_stats, (size_t)m * 6 * sizeof(double),
+                              hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+  }
+  return SLAMHIP_OK;
+}
+
 static int single_prepare(slamhip_ctx* c, const double* params) {
   if (!c || c->wgroup < 1) return SLAMHIP_ERR_STATE;
   if (!params) return fail(c, SLAMHIP_ERR_ARG, "null params");
@@ -1215,7 +1397,8 @@ int slamhip_surface(slamhip_ctx* c, const double* params, int slot, double* x_ou
   if (slot < 0 || slot > 3 || !x_out || !v_out) return fail(c, SLAMHIP_ERR_ARG, "surface: bad arguments");
   const FitK& k = c->k;
   hipLaunchKernelGGL(k_prep, dim3(1), dim3(64), 0, c->stream, k, c->d_params, 1, c->d_wk,
-                     c->d_cellx, c->d_fracx, c->d_celly, c->d_fracy);
+                     c->d_cellx, c->d_fracx, c->d_celly, c->d_fracy, c->d_tile_ix,
+                     c->d_tile_jy, (int)c->fz_grid.x, (int)c->fz_grid.y, c->fz_sx, c->fz_sy);
   WalkerK hw;
   HIP_TRY(c, hipMemcpyAsync(&hw, c->d_wk, sizeof hw, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -1241,7 +1424,8 @@ int slamhip_prof(slamhip_ctx* c, double cs, double* prof_out, double* prof_d_out
   int rc = single_prepare(c, p);
   if (rc) return rc;
   hipLaunchKernelGGL(k_prep, dim3(1), dim3(64), 0, c->stream, c->k, c->d_params, 1, c->d_wk,
-                     c->d_cellx, c->d_fracx, c->d_celly, c->d_fracy);
+                     c->d_cellx, c->d_fracx, c->d_celly, c->d_fracy, c->d_tile_ix,
+                     c->d_tile_jy, (int)c->fz_grid.x, (int)c->fz_grid.y, c->fz_sx, c->fz_sy);
   WalkerK hw;
   HIP_TRY(c, hipMemcpyAsync(&hw, c->d_wk, sizeof hw, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));

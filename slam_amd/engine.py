@@ -128,6 +128,17 @@ class HipLikelihood:
                 self._ctx, as_dp(a), a.shape[0], as_dp(out)), 'chi2_batch')
         return out
 
+    def chi2_stats(self, P):
+        """Hot path with get_scale's sums exposed: dict of arrays gf, ff, scale,
+        chi2, live_tiles, tiles (one entry per row of P)."""
+        a = self._params(P, True)
+        st = np.empty((a.shape[0], 6), dtype=np.float64)
+        if a.shape[0]:
+            self._check(self._lib.slamhip_chi2_stats(
+                self._ctx, as_dp(a), a.shape[0], as_dp(st)), 'chi2_stats')
+        return dict(gf=st[:, 0], ff=st[:, 1], scale=st[:, 2], chi2=st[:, 3],
+                    live_tiles=st[:, 4], tiles=st[:, 5])
+
     def chi2_batch_torch(self, P, out=None, stream=None):
         """Same, for a float64 CUDA tensor P[nw, 13]; enqueued on torch's
         current stream (or `stream`), returns a CUDA tensor without syncing."""

@@ -111,6 +111,18 @@ def test_cubemodel_and_stats_golden(case):
             assert _golden.relmax(model, g[pre + 'model']) < CUBE_TOL, name
 
 
+def test_hot_path_sums_golden(case):
+    """gf, ff, scale, chi2 of the batched (fused conv+regrid+reduce) path."""
+    g, s, eng = case
+    names = _golden.vectors(g)
+    P = np.array([g[f'vec_{n}_p'] for n in names])
+    st = eng.chi2_stats(P)
+    for key in ('gf', 'ff', 'scale', 'chi2'):
+        ref = np.array([float(g[f'vec_{n}_{key}']) for n in names])
+        np.testing.assert_allclose(st[key], ref, rtol=1e-9, atol=1e-300, err_msg=key)
+    assert np.all(st['live_tiles'] <= st['tiles'])
+
+
 def test_noconv_golden(case):
     g, s, eng = case
     name = _golden.vectors(g)[0]
