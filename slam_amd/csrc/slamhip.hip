@@ -40,6 +40,7 @@ constexpr int CH = 32;                       // channels accumulated in register
 constexpr int CONV_TX = 64;                  // conv tile width (= one wave)
 constexpr int CONV_R = 8;                    // outputs per thread along the tap axis
 constexpr int RED_THREADS = 256;
+constexpr int FLAG_MAX = 512;                // occupancy bytes one conv window may span
 
 // ---------------------------------------------------------------------------
 // Device-resident constants of one fit (what makegrid leaves on `self`).
@@ -352,24 +353,43 @@ __device__ inline int prof_index(double vk, double vl, double o, double rinv,
   return min(max(idx, 0), PROF_N);
 }
 
+constexpr int PT_X = 32, PT_Y = 8;   // k_profile tile: 256 pixels, 2 rows per wave
+
+__device__ inline unsigned wave_or(unsigned v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v |= __shfl_xor(v, off, 64);
+  return v;
+}
+
+// Iunif is sparse (a channel map is mostly empty sky), so each (walker,
+// channel, 32x8 tile) gets an occupancy byte and only occupied tiles are
+// written.  Consumers either honour the flags (k_conv_chi2) or are handed a
+// pre-zeroed buffer (dense taps).
 __global__ void __launch_bounds__(256)
 k_profile(FitK g, const WalkerK* __restrict__ wk,
           const double* __restrict__ vl_in, const double* __restrict__ wt_in,
-          double* __restrict__ iunif) {
+          double* __restrict__ iunif, unsigned char* __restrict__ flags) {
   __shared__ double s_prof[PROF_LEN];
+  __shared__ unsigned s_mask[4];
   const int wi = blockIdx.z;
   const WalkerK& w = wk[wi];
-  if (threadIdx.x < PROF_LEN) s_prof[threadIdx.x] = w.prof[threadIdx.x];
+  const int tid = threadIdx.x;
+  if (tid < PROF_LEN) s_prof[tid] = w.prof[tid];
   __syncthreads();
-  const int npx = g.nneed * g.nneed;
-  const int pix = blockIdx.x * blockDim.x + threadIdx.x;
-  if (pix >= npx) return;
-  const int l0 = g.leaf_off[pix], l1 = g.leaf_off[pix + 1];
+  const int n = g.nneed;
+  const int npx = n * n;
+  const int x = blockIdx.x * PT_X + (tid & (PT_X - 1));
+  const int y = blockIdx.y * PT_Y + tid / PT_X;
+  const bool inb = x < n && y < n;
+  const int pix = inb ? y * n + x : 0;
+  const int l0 = inb ? g.leaf_off[pix] : 0, l1 = inb ? g.leaf_off[pix + 1] : 0;
   const int nsurf = w.nsurf;
   const double rinv = w.rinv, hw = w.halfwidth, voff = w.voff;
   const double* vlw = vl_in + (long long)wi * 4 * g.nleaf;
   const double* wtw = wt_in + (long long)wi * 4 * g.nleaf;
   double* out = iunif + (long long)wi * g.nv * npx + pix;
+  const long long ftile = (long long)gridDim.y * gridDim.x;
+  unsigned char* fl = flags + (long long)wi * g.nv * ftile + (long long)blockIdx.y * gridDim.x + blockIdx.x;
   const int nchunk = g.nvpad / CH;
   for (int cix = 0; cix < nchunk; ++cix) {
     double acc[CH];
@@ -377,11 +397,13 @@ k_profile(FitK g, const WalkerK* __restrict__ wk,
     for (int c = 0; c < CH; ++c) acc[c] = 0.0;
     const double cmin = g.ch_vmin[cix], cmax = g.ch_vmax[cix];
     const double* vk = g.vpad + cix * CH;
+    bool hit = false;
     for (int s = 0; s < nsurf; ++s) {
       for (int lf = l0; lf < l1; ++lf) {
         const double vl = vlw[(long long)s * g.nleaf + lf];
         const double o = vl + voff;
         if (cmin - o > hw || o - cmax > hw) continue;     // no channel of this block is lit
+        hit = true;
         const double wt = wtw[(long long)s * g.nleaf + lf];
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
@@ -390,11 +412,25 @@ k_profile(FitK g, const WalkerK* __restrict__ wk,
         }
       }
     }
+    const int kf = cix * CH + tid;                        // flag writer: thread c -> channel c
+    if (!__syncthreads_or(hit)) {
+      if (tid < CH && kf < g.nv) fl[(long long)kf * ftile] = 0;
+      continue;
+    }
+    unsigned m = 0;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) m |= (unsigned)(acc[c] != 0.0) << c;
+    m = wave_or(m);
+    if ((tid & 63) == 0) s_mask[tid >> 6] = m;
+    __syncthreads();
+    m = s_mask[0] | s_mask[1] | s_mask[2] | s_mask[3];
+    if (tid < CH && kf < g.nv) fl[(long long)kf * ftile] = (m >> tid) & 1u;
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
       const int k = cix * CH + c;
-      if (k < g.nv) out[(long long)k * npx] = acc[c];
+      if (((m >> c) & 1u) && inb && k < g.nv) out[(long long)k * npx] = acc[c];
     }
+    __syncthreads();                                      // s_mask reused next chunk
   }
 }
 
@@ -423,8 +459,11 @@ struct ConvAcc {
 // (wave + 4q)*R .. +R-1 of column `lane`.  Returns false (nothing computed)
 // when the staged input tile is all zero.  Leaves the block past a barrier:
 // LDS may be reused after one more __syncthreads().
+// `fl` (may be null = dense input): occupancy bytes of this plane's 32x8 tiles,
+// `ftx`/`fty` tiles per row/column; tiles flagged 0 are not read.
 template <int TY, int MAXR>
 __device__ inline bool conv_tile(const FitK& g, const double* __restrict__ src,
+                                 const unsigned char* __restrict__ fl, int ftx, int fty,
                                  int x0, int y0, int kpad, double* lds,
                                  ConvAcc<TY>& acc) {
   constexpr int TX = CONV_TX, R = CONV_R;
@@ -440,18 +479,36 @@ __device__ inline bool conv_tile(const FitK& g, const double* __restrict__ src,
   //    the first LDS write.
   const int lane = tid & 63, wv = tid >> 6;
   const int vrows = TY + K - 1, vcols = TX + K - 1;
+  // occupancy of the 32x8 input tiles under this window
+  __shared__ unsigned char s_fl[FLAG_MAX];
+  const int ftx0 = max(x0 - ng, 0) / PT_X, fty0 = max(y0 - ng, 0) / PT_Y;
+  const int fnx = min(x0 - ng + vcols - 1, n - 1) / PT_X - ftx0 + 1;
+  const int fny = min(y0 - ng + vrows - 1, n - 1) / PT_Y - fty0 + 1;
+  if (fl) {
+    bool some = false;
+    for (int e = tid; e < fnx * fny; e += 256) {
+      const int fy = e / fnx, fx = e - fy * fnx;
+      const unsigned char f = fl[(long long)(fty0 + fy) * ftx + ftx0 + fx];
+      s_fl[e] = f;
+      some |= f != 0;
+    }
+    if (!__syncthreads_or(some)) return false;             // nothing but empty sky
+  }
   bool any = false;
   for (int c0 = 0; c0 < P; c0 += 64) {
     const int cc = c0 + lane;
     const int gx = x0 - ng + cc;
     const bool colok = cc < vcols && gx >= 0 && gx < n;
+    const int fxl = colok ? gx / PT_X - ftx0 : 0;
     for (int r0 = wv; r0 < rows; r0 += 4 * 8) {
       double v[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const int rr = r0 + 4 * u;
         const int gy = y0 - ng + rr;
-        v[u] = (colok && rr < vrows && gy >= 0 && gy < n) ? src[(long long)gy * n + gx] : 0.0;
+        bool ok = colok && rr < vrows && gy >= 0 && gy < n;
+        if (fl && ok) ok = s_fl[(gy / PT_Y - fty0) * fnx + fxl] != 0;
+        v[u] = ok ? src[(long long)gy * n + gx] : 0.0;
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
@@ -542,7 +599,7 @@ k_conv_sep(FitK g, const double* __restrict__ in, double* __restrict__ out,
   const int x0 = blockIdx.x * TX, y0 = blockIdx.y * TY;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   ConvAcc<TY> acc;
-  if (!conv_tile<TY, MAXR>(g, src, x0, y0, kpad, lds, acc)) {
+  if (!conv_tile<TY, MAXR>(g, src, nullptr, 0, 0, x0, y0, kpad, lds, acc)) {
     for (int e = tid; e < TX * TY; e += 256) {
       const int gy = y0 + e / TX, gxo = x0 + (e & (TX - 1));
       if (gxo < n && gy < n) dst[(long long)gy * n + gxo] = 0.0;
@@ -572,6 +629,7 @@ k_conv_chi2(FitK g, const double* __restrict__ iunif,
             const int* __restrict__ cellx, const double* __restrict__ fracx,
             const int* __restrict__ celly, const double* __restrict__ fracy,
             const int* __restrict__ tile_ix, const int* __restrict__ tile_jy,
+            const unsigned char* __restrict__ flags, int ftx, int fty,
             double* __restrict__ partial, int kpad) {
   extern __shared__ double lds[];
   constexpr int TX = CONV_TX, R = CONV_R, PC = TX + 1;
@@ -582,7 +640,8 @@ k_conv_chi2(FitK g, const double* __restrict__ iunif,
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const long long blk = ((long long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
   ConvAcc<TY> acc;
-  if (!conv_tile<TY, MAXR>(g, src, x0, y0, kpad, lds, acc)) {
+  const unsigned char* fl = flags + (long long)blockIdx.z * ftx * fty;
+  if (!conv_tile<TY, MAXR>(g, src, fl, ftx, fty, x0, y0, kpad, lds, acc)) {
     if (tid == 0) { partial[3 * blk] = 0.0; partial[3 * blk + 1] = 0.0; partial[3 * blk + 2] = 0.0; }
     return;
   }
@@ -822,6 +881,8 @@ struct slamhip_ctx {
   int* d_celly = nullptr;
   double* d_fracx = nullptr;
   double* d_fracy = nullptr;
+  unsigned char* d_flags = nullptr;   // [walker][nv][fty][ftx] occupancy of Iunif tiles
+  int ftx = 1, fty = 1;
   int* d_tile_ix = nullptr;
   int* d_tile_jy = nullptr;
   int fused = 0;           // hot path uses k_conv_chi2
@@ -975,8 +1036,12 @@ int run_conv(slamhip_ctx* c, const double* in, double* out, int planes,
 }
 
 // Stages shared by every entry point: params (device) -> iunif for `nw` walkers
-int run_model(slamhip_ctx* c, const double* d_params, int nw, hipStream_t st) {
+// `dense`: the consumer reads Iunif without the occupancy flags, so tiles that
+// k_profile skips must already hold zeros.
+int run_model(slamhip_ctx* c, const double* d_params, int nw, hipStream_t st, bool dense) {
   const FitK& k = c->k;
+  if (dense)
+    HIP_TRY(c, hipMemsetAsync(c->d_iunif, 0, sizeof(double) * (size_t)nw * k.nv * k.nneed * k.nneed, st));
   {
     Timed t_(c, KID_PREP, st);
     hipLaunchKernelGGL(k_prep, dim3(nw), dim3(64), 0, st, k, d_params, nw, c->d_wk,
@@ -990,9 +1055,9 @@ int run_model(slamhip_ctx* c, const double* d_params, int nw, hipStream_t st) {
   }
   {
     Timed t_(c, KID_PROFILE, st);
-    dim3 g2((k.nneed * k.nneed + 255) / 256, 1, nw);
+    dim3 g2(c->ftx, c->fty, nw);
     hipLaunchKernelGGL(k_profile, g2, dim3(256), 0, st, k, c->d_wk, c->d_vl, c->d_wt,
-                       c->d_iunif);
+                       c->d_iunif, c->d_flags);
   }
   HIP_TRY(c, hipGetLastError());
   return SLAMHIP_OK;
@@ -1000,9 +1065,10 @@ int run_model(slamhip_ctx* c, const double* d_params, int nw, hipStream_t st) {
 
 int run_group(slamhip_ctx* c, const double* d_params, int nw, double* d_chi2,
               hipStream_t st) {
-  int rc = run_model(c, d_params, nw, st);
+  const bool fused = c->fused && c->conv_mode == 0;
+  int rc = run_model(c, d_params, nw, st, !fused);
   if (rc) return rc;
-  if (c->fused && c->conv_mode == 0) {
+  if (fused) {
     {
       Timed t_(c, KID_CONV, st);
       dim3 gz(c->fz_grid.x, c->fz_grid.y, c->fz_grid.z * nw);
@@ -1011,7 +1077,8 @@ int run_group(slamhip_ctx* c, const double* d_params, int nw, double* d_chi2,
 #define SLAM_FUSED(TY_, MR_)                                                              \
       hipLaunchKernelGGL((k_conv_chi2<TY_, MR_>), gz, dim3(256), c->sep_lds, st, c->k,    \
                          c->d_iunif, c->d_cellx, c->d_fracx, c->d_celly, c->d_fracy,       \
-                         c->d_tile_ix, c->d_tile_jy, c->d_partial, c->kpad)
+                         c->d_tile_ix, c->d_tile_jy, c->d_flags, c->ftx, c->fty,           \
+                         c->d_partial, c->kpad)
       switch (c->sep_variant) {
         case 0: SLAM_FUSED(64, 3); break;
         case 1: SLAM_FUSED(64, 5); break;
@@ -1211,6 +1278,15 @@ int slamhip_create(const slamhip_desc* d, slamhip_ctx** out) {
   if ((rc = dev_alloc(c, &c->d_fracx, W * k.nx))) return rc;
   if ((rc = dev_alloc(c, &c->d_celly, W * k.ny))) return rc;
   if ((rc = dev_alloc(c, &c->d_fracy, W * k.ny))) return rc;
+  c->ftx = (n + PT_X - 1) / PT_X;
+  c->fty = (n + PT_Y - 1) / PT_Y;
+  if ((rc = dev_alloc(c, &c->d_flags, W * k.nv * c->ftx * c->fty))) return rc;
+  {
+    // a conv window must not span more occupancy bytes than its LDS table holds
+    const int ty = c->sep_variant == 2 ? 32 : 64;
+    const int spanx = (CONV_TX + K - 2) / PT_X + 2, spany = (ty + K - 2) / PT_Y + 2;
+    if (c->fused && spanx * spany > FLAG_MAX) c->fused = 0;
+  }
   if ((rc = dev_alloc(c, &c->d_tile_ix, W * c->fz_grid.x * 2))) return rc;
   if ((rc = dev_alloc(c, &c->d_tile_jy, W * c->fz_grid.y * 2))) return rc;
   HIP_TRY(c, hipStreamCreate(&c->stream));
@@ -1340,7 +1416,7 @@ static int single_prepare(slamhip_ctx* c, const double* params) {
 int slamhip_iunif(slamhip_ctx* c, const double* params, double* out) {
   int rc = single_prepare(c, params);
   if (rc) return rc;
-  if ((rc = run_model(c, c->d_params, 1, c->stream))) return rc;
+  if ((rc = run_model(c, c->d_params, 1, c->stream, true))) return rc;
   const size_t nb = (size_t)c->k.nv * c->k.nneed * c->k.nneed * sizeof(double);
   HIP_TRY(c, hipMemcpyAsync(out, c->d_iunif, nb, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -1350,7 +1426,7 @@ int slamhip_iunif(slamhip_ctx* c, const double* params, double* out) {
 int slamhip_iconv(slamhip_ctx* c, const double* params, double* out) {
   int rc = single_prepare(c, params);
   if (rc) return rc;
-  if ((rc = run_model(c, c->d_params, 1, c->stream))) return rc;
+  if ((rc = run_model(c, c->d_params, 1, c->stream, true))) return rc;
   if ((rc = run_conv(c, c->d_iunif, c->d_iconv, c->k.nv, c->stream))) return rc;
   const size_t nb = (size_t)c->k.nv * c->k.nneed * c->k.nneed * sizeof(double);
   HIP_TRY(c, hipMemcpyAsync(out, c->d_iconv, nb, hipMemcpyDeviceToHost, c->stream));
@@ -1364,7 +1440,7 @@ int slamhip_cubemodel(slamhip_ctx* c, const double* params, int convolving,
   if (rc) return rc;
   if (!out) return fail(c, SLAMHIP_ERR_ARG, "null output");
   const FitK& k = c->k;
-  if ((rc = run_model(c, c->d_params, 1, c->stream))) return rc;
+  if ((rc = run_model(c, c->d_params, 1, c->stream, true))) return rc;
   if (convolving) {
     if ((rc = run_conv(c, c->d_iunif, c->d_iconv, k.nv, c->stream))) return rc;
   } else {
