@@ -368,9 +368,11 @@ __device__ inline unsigned wave_or(unsigned v) {
 __global__ void __launch_bounds__(256)
 k_profile(FitK g, const WalkerK* __restrict__ wk,
           const double* __restrict__ vl_in, const double* __restrict__ wt_in,
-          double* __restrict__ iunif, unsigned char* __restrict__ flags) {
+          double* __restrict__ iunif, unsigned char* __restrict__ flags,
+          unsigned char* __restrict__ winflag, int wnx, int wny, int wsx, int wsy) {
   __shared__ double s_prof[PROF_LEN];
   __shared__ unsigned s_mask[4];
+  __shared__ unsigned s_cmask[4];
   const int wi = blockIdx.z;
   const WalkerK& w = wk[wi];
   const int tid = threadIdx.x;
@@ -391,7 +393,31 @@ k_profile(FitK g, const WalkerK* __restrict__ wk,
   const long long ftile = (long long)gridDim.y * gridDim.x;
   unsigned char* fl = flags + (long long)wi * g.nv * ftile + (long long)blockIdx.y * gridDim.x + blockIdx.x;
   const int nchunk = g.nvpad / CH;
+  // which channel blocks does any sample of this tile light up?  (one pass over
+  // the samples; blocks nobody lights are skipped without touching memory again)
+  unsigned cm = 0;
+  for (int s = 0; s < nsurf; ++s)
+    for (int lf = l0; lf < l1; ++lf) {
+      const double o = vlw[(long long)s * g.nleaf + lf] + voff;
+      for (int cix = 0; cix < nchunk && cix < 32; ++cix)
+        if (!(g.ch_vmin[cix] - o > hw || o - g.ch_vmax[cix] > hw)) cm |= 1u << cix;
+    }
+  cm = wave_or(cm);
+  if ((tid & 63) == 0) s_cmask[tid >> 6] = cm;
+  __syncthreads();
+  cm = s_cmask[0] | s_cmask[1] | s_cmask[2] | s_cmask[3];
+  // conv windows (k_conv_chi2 tiles incl. beam halo) this tile feeds
+  const int px0 = blockIdx.x * PT_X, py0 = blockIdx.y * PT_Y;
+  const int wbx0 = max(0, (px0 - (CONV_TX - 1) - g.ngauss + wsx - 1) / wsx);
+  const int wbx1 = min(wnx - 1, (px0 + PT_X - 1 + g.ngauss) / wsx);
+  const int wby0 = max(0, (py0 - wsy - g.ngauss + wsy - 1) / wsy);
+  const int wby1 = min(wny - 1, (py0 + PT_Y - 1 + g.ngauss) / wsy);
   for (int cix = 0; cix < nchunk; ++cix) {
+    const int kf = cix * CH + tid;                        // flag writer: thread c -> channel c
+    if (cix < 32 && !((cm >> cix) & 1u)) {
+      if (tid < CH && kf < g.nv) fl[(long long)kf * ftile] = 0;
+      continue;
+    }
     double acc[CH];
 #pragma unroll
     for (int c = 0; c < CH; ++c) acc[c] = 0.0;
@@ -412,7 +438,6 @@ k_profile(FitK g, const WalkerK* __restrict__ wk,
         }
       }
     }
-    const int kf = cix * CH + tid;                        // flag writer: thread c -> channel c
     if (!__syncthreads_or(hit)) {
       if (tid < CH && kf < g.nv) fl[(long long)kf * ftile] = 0;
       continue;
@@ -424,7 +449,14 @@ k_profile(FitK g, const WalkerK* __restrict__ wk,
     if ((tid & 63) == 0) s_mask[tid >> 6] = m;
     __syncthreads();
     m = s_mask[0] | s_mask[1] | s_mask[2] | s_mask[3];
-    if (tid < CH && kf < g.nv) fl[(long long)kf * ftile] = (m >> tid) & 1u;
+    if (tid < CH && kf < g.nv) {
+      fl[(long long)kf * ftile] = (m >> tid) & 1u;
+      if ((m >> tid) & 1u) {                              // mark the windows to convolve
+        unsigned char* wf = winflag + ((long long)wi * g.nv + kf) * wnx * wny;
+        for (int by = wby0; by <= wby1; ++by)
+          for (int bx = wbx0; bx <= wbx1; ++bx) wf[by * wnx + bx] = 1;
+      }
+    }
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
       const int k = cix * CH + c;
@@ -616,6 +648,15 @@ k_conv_sep(FitK g, const double* __restrict__ in, double* __restrict__ out,
     }
 }
 
+// k_compact: list of conv windows that contain emission (order irrelevant:
+// every window writes its partial sums to its own slot).
+__global__ void __launch_bounds__(256)
+k_compact(const unsigned char* __restrict__ winflag, int total, int* __restrict__ list,
+          int* __restrict__ count) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e < total && winflag[e]) list[atomicAdd(count, 1)] = e;
+}
+
 // k_conv_chi2: the hot-path form.  Convolves a tile, keeps it in LDS, regrids
 // it bilinearly onto the observed pixels whose interpolation cell it owns
 // (:475-483) and reduces sum(I*d), sum(I*I) for get_scale (:485-490): wave
@@ -630,20 +671,30 @@ k_conv_chi2(FitK g, const double* __restrict__ iunif,
             const int* __restrict__ celly, const double* __restrict__ fracy,
             const int* __restrict__ tile_ix, const int* __restrict__ tile_jy,
             const unsigned char* __restrict__ flags, int ftx, int fty,
+            const int* __restrict__ list, const int* __restrict__ count, int wnx, int wny,
             double* __restrict__ partial, int kpad) {
   extern __shared__ double lds[];
   constexpr int TX = CONV_TX, R = CONV_R, PC = TX + 1;
+  __shared__ double sg[4], sf[4];
   const int n = g.nneed;
-  const int wi = blockIdx.z / g.nv, k = blockIdx.z - wi * g.nv;
-  const double* src = iunif + (long long)blockIdx.z * n * n;
-  const int x0 = blockIdx.x * (TX - 1), y0 = blockIdx.y * (TY - 1);
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const long long blk = ((long long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+  const int nlive = *count;
+  // persistent blocks stride over the live-window list; every wave reaches the
+  // loop exit after ceil(nlive / gridDim.x) iterations
+  for (int it = blockIdx.x; it < nlive; it += gridDim.x) {
+  const int e = list[it];
+  const int z = e / (wnx * wny), tl = e - z * (wnx * wny);
+  const int tby = tl / wnx, tbx = tl - tby * wnx;
+  const int wi = z / g.nv, k = z - wi * g.nv;
+  const double* src = iunif + (long long)z * n * n;
+  const int x0 = tbx * (TX - 1), y0 = tby * (TY - 1);
+  const long long blk = e;
   ConvAcc<TY> acc;
-  const unsigned char* fl = flags + (long long)blockIdx.z * ftx * fty;
+  const unsigned char* fl = flags + (long long)z * ftx * fty;
   if (!conv_tile<TY, MAXR>(g, src, fl, ftx, fty, x0, y0, kpad, lds, acc)) {
     if (tid == 0) { partial[3 * blk] = 0.0; partial[3 * blk + 1] = 0.0; partial[3 * blk + 2] = 0.0; }
-    return;
+    __syncthreads();
+    continue;
   }
   __syncthreads();                         // column pass done reading LDS
 #pragma unroll
@@ -651,8 +702,8 @@ k_conv_chi2(FitK g, const double* __restrict__ iunif,
 #pragma unroll
     for (int r = 0; r < R; ++r) lds[((wv + 4 * q) * R + r) * PC + lane] = acc.v[q][r];
   __syncthreads();
-  const int* tix = tile_ix + ((long long)wi * gridDim.x + blockIdx.x) * 2;
-  const int* tjy = tile_jy + ((long long)wi * gridDim.y + blockIdx.y) * 2;
+  const int* tix = tile_ix + ((long long)wi * wnx + tbx) * 2;
+  const int* tjy = tile_jy + ((long long)wi * wny + tby) * 2;
   const int ixa = tix[0], ixb = tix[1], jya = tjy[0], jyb = tjy[1];
   const int* cx = cellx + (long long)wi * g.nx;
   const int* cy = celly + (long long)wi * g.ny;
@@ -676,7 +727,6 @@ k_conv_chi2(FitK g, const double* __restrict__ iunif,
       ff = fma(val, val, ff);
     }
   }
-  __shared__ double sg[4], sf[4];
   gf = wave_sum(gf);
   ff = wave_sum(ff);
   if (lane == 0) { sg[wv] = gf; sf[wv] = ff; }
@@ -685,6 +735,8 @@ k_conv_chi2(FitK g, const double* __restrict__ iunif,
     partial[3 * blk] = (sg[0] + sg[1]) + (sg[2] + sg[3]);
     partial[3 * blk + 1] = (sf[0] + sf[1]) + (sf[2] + sf[3]);
     partial[3 * blk + 2] = 1.0;                            // tile was not empty
+  }
+  __syncthreads();                         // LDS is restaged by the next window
   }
 }
 
@@ -818,11 +870,14 @@ k_regrid(FitK g, const int* __restrict__ cellx, const double* __restrict__ fracx
 // stats[w] = {gf, ff, scale, chi2, non-empty blocks, blocks}
 __global__ void __launch_bounds__(64)
 k_finalize(FitK g, const double* __restrict__ partial, int nblk,
+           const unsigned char* __restrict__ winflag,
            double* __restrict__ stats, double* __restrict__ chi2_out) {
   const int wi = blockIdx.x;
   const double* p = partial + (long long)wi * nblk * 3;
+  const unsigned char* wf = winflag ? winflag + (long long)wi * nblk : nullptr;
   double a = 0.0, b = 0.0, live = 0.0;
   for (int q = threadIdx.x; q < nblk; q += 64) {
+    if (wf && !wf[q]) continue;          // window never convolved: its slot is stale
     a += p[3 * q]; b += p[3 * q + 1]; live += p[3 * q + 2];
   }
   a = wave_sum(a);
@@ -883,6 +938,10 @@ struct slamhip_ctx {
   double* d_fracy = nullptr;
   unsigned char* d_flags = nullptr;   // [walker][nv][fty][ftx] occupancy of Iunif tiles
   int ftx = 1, fty = 1;
+  unsigned char* d_winflag = nullptr; // [walker][nv][wny][wnx] conv windows with emission (+ counter)
+  int* d_livelist = nullptr;
+  int* d_livecount = nullptr;
+  int persist_blocks = 1;
   int* d_tile_ix = nullptr;
   int* d_tile_jy = nullptr;
   int fused = 0;           // hot path uses k_conv_chi2
@@ -902,9 +961,9 @@ struct slamhip_ctx {
   std::vector<Span> spans;
 };
 
-enum KernelId { KID_PREP = 0, KID_SURFACE, KID_PROFILE, KID_CONV, KID_REGRID, KID_FINALIZE, KID_COUNT };
+enum KernelId { KID_PREP = 0, KID_SURFACE, KID_PROFILE, KID_COMPACT, KID_CONV, KID_REGRID, KID_FINALIZE, KID_COUNT };
 static const char* const kKernelNames[KID_COUNT] = {
-    "k_prep", "k_surface", "k_profile", "k_conv", "k_regrid", "k_finalize"};
+    "k_prep", "k_surface", "k_profile", "k_compact", "k_conv", "k_regrid", "k_finalize"};
 
 // Brackets one launch with events on the launch stream when profiling is on.
 struct Timed {
@@ -1042,6 +1101,9 @@ int run_model(slamhip_ctx* c, const double* d_params, int nw, hipStream_t st, bo
   const FitK& k = c->k;
   if (dense)
     HIP_TRY(c, hipMemsetAsync(c->d_iunif, 0, sizeof(double) * (size_t)nw * k.nv * k.nneed * k.nneed, st));
+  // window marks + live counter start at zero every group
+  HIP_TRY(c, hipMemsetAsync(c->d_winflag, 0, (size_t)nw * k.nv * c->fz_grid.x * c->fz_grid.y, st));
+  HIP_TRY(c, hipMemsetAsync(c->d_livecount, 0, 256, st));
   {
     Timed t_(c, KID_PREP, st);
     hipLaunchKernelGGL(k_prep, dim3(nw), dim3(64), 0, st, k, d_params, nw, c->d_wk,
@@ -1057,7 +1119,8 @@ int run_model(slamhip_ctx* c, const double* d_params, int nw, hipStream_t st, bo
     Timed t_(c, KID_PROFILE, st);
     dim3 g2(c->ftx, c->fty, nw);
     hipLaunchKernelGGL(k_profile, g2, dim3(256), 0, st, k, c->d_wk, c->d_vl, c->d_wt,
-                       c->d_iunif, c->d_flags);
+                       c->d_iunif, c->d_flags, c->d_winflag, (int)c->fz_grid.x, (int)c->fz_grid.y,
+                       c->fz_sx, c->fz_sy);
   }
   HIP_TRY(c, hipGetLastError());
   return SLAMHIP_OK;
@@ -1069,15 +1132,20 @@ int run_group(slamhip_ctx* c, const double* d_params, int nw, double* d_chi2,
   int rc = run_model(c, d_params, nw, st, !fused);
   if (rc) return rc;
   if (fused) {
+    const int nwin = (int)(c->fz_grid.x * c->fz_grid.y * c->fz_grid.z) * nw;
+    {
+      Timed t_(c, KID_COMPACT, st);
+      hipLaunchKernelGGL(k_compact, dim3((nwin + 255) / 256), dim3(256), 0, st, c->d_winflag, nwin,
+                         c->d_livelist, c->d_livecount);
+    }
     {
       Timed t_(c, KID_CONV, st);
-      dim3 gz(c->fz_grid.x, c->fz_grid.y, c->fz_grid.z * nw);
-      const int nblk = (int)(c->fz_grid.x * c->fz_grid.y * c->fz_grid.z);
-      (void)nblk;
+      dim3 gz(c->persist_blocks, 1, 1);
 #define SLAM_FUSED(TY_, MR_)                                                              \
       hipLaunchKernelGGL((k_conv_chi2<TY_, MR_>), gz, dim3(256), c->sep_lds, st, c->k,    \
                          c->d_iunif, c->d_cellx, c->d_fracx, c->d_celly, c->d_fracy,       \
                          c->d_tile_ix, c->d_tile_jy, c->d_flags, c->ftx, c->fty,           \
+                         c->d_livelist, c->d_livecount, (int)c->fz_grid.x, (int)c->fz_grid.y, \
                          c->d_partial, c->kpad)
       switch (c->sep_variant) {
         case 0: SLAM_FUSED(64, 3); break;
@@ -1089,7 +1157,8 @@ int run_group(slamhip_ctx* c, const double* d_params, int nw, double* d_chi2,
     {
       Timed t_(c, KID_FINALIZE, st);
       hipLaunchKernelGGL(k_finalize, dim3(nw), dim3(64), 0, st, c->k, c->d_partial,
-                         (int)(c->fz_grid.x * c->fz_grid.y * c->fz_grid.z), c->d_stats, d_chi2);
+                         (int)(c->fz_grid.x * c->fz_grid.y * c->fz_grid.z), c->d_winflag,
+                         c->d_stats, d_chi2);
     }
     HIP_TRY(c, hipGetLastError());
     return SLAMHIP_OK;
@@ -1106,7 +1175,7 @@ int run_group(slamhip_ctx* c, const double* d_params, int nw, double* d_chi2,
   {
     Timed t_(c, KID_FINALIZE, st);
     hipLaunchKernelGGL(k_finalize, dim3(nw), dim3(64), 0, st, c->k, c->d_partial,
-                       c->red_blocks, c->d_stats, d_chi2);
+                       c->red_blocks, (const unsigned char*)nullptr, c->d_stats, d_chi2);
   }
   HIP_TRY(c, hipGetLastError());
   return SLAMHIP_OK;
@@ -1287,6 +1356,16 @@ int slamhip_create(const slamhip_desc* d, slamhip_ctx** out) {
     const int spanx = (CONV_TX + K - 2) / PT_X + 2, spany = (ty + K - 2) / PT_Y + 2;
     if (c->fused && spanx * spany > FLAG_MAX) c->fused = 0;
   }
+  {
+    const size_t nwin = W * k.nv * c->fz_grid.x * c->fz_grid.y;
+    if ((rc = dev_alloc(c, &c->d_winflag, nwin))) return rc;
+    if ((rc = dev_alloc(c, &c->d_livelist, nwin))) return rc;
+    if ((rc = dev_alloc(c, &c->d_livecount, 64))) return rc;
+    hipDeviceProp_t prop;
+    HIP_TRY(c, hipGetDeviceProperties(&prop, c->device));
+    const int per_cu = std::max(1, (int)((160 * 1024) / std::max<size_t>(c->sep_lds + 1024, 1)));
+    c->persist_blocks = prop.multiProcessorCount * std::min(per_cu, 8);
+  }
   if ((rc = dev_alloc(c, &c->d_tile_ix, W * c->fz_grid.x * 2))) return rc;
   if ((rc = dev_alloc(c, &c->d_tile_jy, W * c->fz_grid.y * 2))) return rc;
   HIP_TRY(c, hipStreamCreate(&c->stream));
@@ -1453,7 +1532,7 @@ int slamhip_cubemodel(slamhip_ctx* c, const double* params, int convolving,
                      c->d_cellx, c->d_fracx, c->d_celly, c->d_fracy, c->d_iconv, c->d_partial,
                      d_cube);
   hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, c->stream, k, c->d_partial, c->red_blocks,
-                     c->d_stats, (double*)nullptr);
+                     (const unsigned char*)nullptr, c->d_stats, (double*)nullptr);
   hipLaunchKernelGGL(k_scale, dim3(1024), dim3(256), 0, c->stream, d_cube, (long long)ncube, c->d_stats);
   hipError_t e = hipGetLastError();
   if (e == hipSuccess)
