@@ -280,10 +280,10 @@ __device__ inline Surf surface_eval(const FitK& g, const WalkerK& w, int s,
 // k_surface: thread per (walker, surviving sample).  Writes, per live surface,
 //   vl = vlos*sqrt(Mstar)          (1e300 where the reference has NaN)
 //   wt = intensity weight * layer-merge weight 4^-layer
-// laid out [walker][surface][sample] so k_profile reads them coalesced.
+// as one {vl, wt} pair laid out [walker][surface][sample] so k_profile reads them
+// coalesced, 16 B per lane.
 __global__ void __launch_bounds__(256)
-k_surface(FitK g, const WalkerK* __restrict__ wk, double* __restrict__ vl_out,
-          double* __restrict__ wt_out) {
+k_surface(FitK g, const WalkerK* __restrict__ wk, double2* __restrict__ geom) {
   const long long leaf = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (leaf >= g.nleaf) return;
   const int wi = blockIdx.z;
@@ -309,9 +309,7 @@ k_surface(FitK g, const WalkerK* __restrict__ wk, double* __restrict__ vl_out,
       if (fabs(wt) > 1.79769313486231570815e308)           // nan_to_num(inf) :468
         wt = copysign(1.79769313486231570815e308, wt);
     }
-    const long long o = ((long long)wi * 4 + s) * g.nleaf + leaf;
-    vl_out[o] = vl;
-    wt_out[o] = wt;
+    geom[((long long)wi * 4 + s) * g.nleaf + leaf] = make_double2(vl, wt);
   }
 }
 
@@ -366,18 +364,16 @@ __device__ inline unsigned wave_or(unsigned v) {
 // written.  Consumers either honour the flags (k_conv_chi2) or are handed a
 // pre-zeroed buffer (dense taps).
 __global__ void __launch_bounds__(256)
-k_profile(FitK g, const WalkerK* __restrict__ wk,
-          const double* __restrict__ vl_in, const double* __restrict__ wt_in,
+k_profile(FitK g, const WalkerK* __restrict__ wk, const double2* __restrict__ geom,
           double* __restrict__ iunif, unsigned char* __restrict__ flags,
           unsigned char* __restrict__ winflag, int wnx, int wny, int wsx, int wsy) {
   __shared__ double s_prof[PROF_LEN];
   __shared__ unsigned s_mask[4];
-  __shared__ unsigned s_cmask[4];
-  const int wi = blockIdx.z;
+  const int nchunk = g.nvpad / CH;
+  const int wi = blockIdx.z / nchunk, cix = blockIdx.z - wi * nchunk;
   const WalkerK& w = wk[wi];
   const int tid = threadIdx.x;
   if (tid < PROF_LEN) s_prof[tid] = w.prof[tid];
-  __syncthreads();
   const int n = g.nneed;
   const int npx = n * n;
   const int x = blockIdx.x * PT_X + (tid & (PT_X - 1));
@@ -387,82 +383,64 @@ k_profile(FitK g, const WalkerK* __restrict__ wk,
   const int l0 = inb ? g.leaf_off[pix] : 0, l1 = inb ? g.leaf_off[pix + 1] : 0;
   const int nsurf = w.nsurf;
   const double rinv = w.rinv, hw = w.halfwidth, voff = w.voff;
-  const double* vlw = vl_in + (long long)wi * 4 * g.nleaf;
-  const double* wtw = wt_in + (long long)wi * 4 * g.nleaf;
-  double* out = iunif + (long long)wi * g.nv * npx + pix;
+  const double2* gw = geom + (long long)wi * 4 * g.nleaf;
   const long long ftile = (long long)gridDim.y * gridDim.x;
   unsigned char* fl = flags + (long long)wi * g.nv * ftile + (long long)blockIdx.y * gridDim.x + blockIdx.x;
-  const int nchunk = g.nvpad / CH;
-  // which channel blocks does any sample of this tile light up?  (one pass over
-  // the samples; blocks nobody lights are skipped without touching memory again)
-  unsigned cm = 0;
-  for (int s = 0; s < nsurf; ++s)
-    for (int lf = l0; lf < l1; ++lf) {
-      const double o = vlw[(long long)s * g.nleaf + lf] + voff;
-      for (int cix = 0; cix < nchunk && cix < 32; ++cix)
-        if (!(g.ch_vmin[cix] - o > hw || o - g.ch_vmax[cix] > hw)) cm |= 1u << cix;
+  const int kf = cix * CH + tid;                          // flag writer: thread c -> channel c
+  const double cmin = g.ch_vmin[cix], cmax = g.ch_vmax[cix];
+  const double* vk = g.vpad + cix * CH;
+  double acc[CH];
+#pragma unroll
+  for (int c = 0; c < CH; ++c) acc[c] = 0.0;
+  bool hit = false;
+  __syncthreads();                                        // s_prof ready
+  for (int lf = l0; lf < l1; ++lf) {
+    double2 q[4];                                         // 4 independent 16-B loads per sample
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+      q[s] = s < nsurf ? gw[(long long)s * g.nleaf + lf] : make_double2(VL_MASKED, 0.0);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const double vl = q[s].x, wt = q[s].y;
+      const double o = vl + voff;
+      if (cmin - o > hw || o - cmax > hw) continue;       // no channel of this block is lit
+      hit = true;
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        const int idx = prof_index(vk[c], vl, o, rinv, g, w);
+        acc[c] = fma(s_prof[idx], wt, acc[c]);
+      }
     }
-  cm = wave_or(cm);
-  if ((tid & 63) == 0) s_cmask[tid >> 6] = cm;
+  }
+  if (!__syncthreads_or(hit)) {                           // empty sky in this channel block
+    if (tid < CH && kf < g.nv) fl[(long long)kf * ftile] = 0;
+    return;
+  }
+  unsigned m = 0;
+#pragma unroll
+  for (int c = 0; c < CH; ++c) m |= (unsigned)(acc[c] != 0.0) << c;
+  m = wave_or(m);
+  if ((tid & 63) == 0) s_mask[tid >> 6] = m;
   __syncthreads();
-  cm = s_cmask[0] | s_cmask[1] | s_cmask[2] | s_cmask[3];
-  // conv windows (k_conv_chi2 tiles incl. beam halo) this tile feeds
-  const int px0 = blockIdx.x * PT_X, py0 = blockIdx.y * PT_Y;
-  const int wbx0 = max(0, (px0 - (CONV_TX - 1) - g.ngauss + wsx - 1) / wsx);
-  const int wbx1 = min(wnx - 1, (px0 + PT_X - 1 + g.ngauss) / wsx);
-  const int wby0 = max(0, (py0 - wsy - g.ngauss + wsy - 1) / wsy);
-  const int wby1 = min(wny - 1, (py0 + PT_Y - 1 + g.ngauss) / wsy);
-  for (int cix = 0; cix < nchunk; ++cix) {
-    const int kf = cix * CH + tid;                        // flag writer: thread c -> channel c
-    if (cix < 32 && !((cm >> cix) & 1u)) {
-      if (tid < CH && kf < g.nv) fl[(long long)kf * ftile] = 0;
-      continue;
+  m = s_mask[0] | s_mask[1] | s_mask[2] | s_mask[3];
+  if (tid < CH && kf < g.nv) {
+    fl[(long long)kf * ftile] = (m >> tid) & 1u;
+    if ((m >> tid) & 1u) {                                // mark the conv windows this tile feeds
+      const int px0 = blockIdx.x * PT_X, py0 = blockIdx.y * PT_Y;
+      const int wbx0 = max(0, (px0 - (CONV_TX - 1) - g.ngauss + wsx - 1) / wsx);
+      const int wbx1 = min(wnx - 1, (px0 + PT_X - 1 + g.ngauss) / wsx);
+      const int wby0 = max(0, (py0 - wsy - g.ngauss + wsy - 1) / wsy);
+      const int wby1 = min(wny - 1, (py0 + PT_Y - 1 + g.ngauss) / wsy);
+      unsigned char* wf = winflag + ((long long)wi * g.nv + kf) * wnx * wny;
+      for (int by = wby0; by <= wby1; ++by)
+        for (int bx = wbx0; bx <= wbx1; ++bx) wf[by * wnx + bx] = 1;
     }
-    double acc[CH];
+  }
+  double* out = iunif + (long long)wi * g.nv * npx + pix;
 #pragma unroll
-    for (int c = 0; c < CH; ++c) acc[c] = 0.0;
-    const double cmin = g.ch_vmin[cix], cmax = g.ch_vmax[cix];
-    const double* vk = g.vpad + cix * CH;
-    bool hit = false;
-    for (int s = 0; s < nsurf; ++s) {
-      for (int lf = l0; lf < l1; ++lf) {
-        const double vl = vlw[(long long)s * g.nleaf + lf];
-        const double o = vl + voff;
-        if (cmin - o > hw || o - cmax > hw) continue;     // no channel of this block is lit
-        hit = true;
-        const double wt = wtw[(long long)s * g.nleaf + lf];
-#pragma unroll
-        for (int c = 0; c < CH; ++c) {
-          const int idx = prof_index(vk[c], vl, o, rinv, g, w);
-          acc[c] = fma(s_prof[idx], wt, acc[c]);
-        }
-      }
-    }
-    if (!__syncthreads_or(hit)) {
-      if (tid < CH && kf < g.nv) fl[(long long)kf * ftile] = 0;
-      continue;
-    }
-    unsigned m = 0;
-#pragma unroll
-    for (int c = 0; c < CH; ++c) m |= (unsigned)(acc[c] != 0.0) << c;
-    m = wave_or(m);
-    if ((tid & 63) == 0) s_mask[tid >> 6] = m;
-    __syncthreads();
-    m = s_mask[0] | s_mask[1] | s_mask[2] | s_mask[3];
-    if (tid < CH && kf < g.nv) {
-      fl[(long long)kf * ftile] = (m >> tid) & 1u;
-      if ((m >> tid) & 1u) {                              // mark the windows to convolve
-        unsigned char* wf = winflag + ((long long)wi * g.nv + kf) * wnx * wny;
-        for (int by = wby0; by <= wby1; ++by)
-          for (int bx = wbx0; bx <= wbx1; ++bx) wf[by * wnx + bx] = 1;
-      }
-    }
-#pragma unroll
-    for (int c = 0; c < CH; ++c) {
-      const int k = cix * CH + c;
-      if (((m >> c) & 1u) && inb && k < g.nv) out[(long long)k * npx] = acc[c];
-    }
-    __syncthreads();                                      // s_mask reused next chunk
+  for (int c = 0; c < CH; ++c) {
+    const int k = cix * CH + c;
+    if (((m >> c) & 1u) && inb && k < g.nv) out[(long long)k * npx] = acc[c];
   }
 }
 
@@ -925,8 +903,7 @@ struct slamhip_ctx {
   int wgroup = 0;          // walkers per launch group
   WalkerK* d_wk = nullptr;
   double* d_params = nullptr;
-  double* d_vl = nullptr;
-  double* d_wt = nullptr;
+  double2* d_geom = nullptr;   // [walker][surface][sample] {vlos*sqrt(M), weight}
   double* d_iunif = nullptr;
   double* d_iconv = nullptr;
   double* d_partial = nullptr;
@@ -1113,12 +1090,12 @@ int run_model(slamhip_ctx* c, const double* d_params, int nw, hipStream_t st, bo
   {
     Timed t_(c, KID_SURFACE, st);
     dim3 g1((unsigned)((k.nleaf + 255) / 256), 1, nw);
-    hipLaunchKernelGGL(k_surface, g1, dim3(256), 0, st, k, c->d_wk, c->d_vl, c->d_wt);
+    hipLaunchKernelGGL(k_surface, g1, dim3(256), 0, st, k, c->d_wk, c->d_geom);
   }
   {
     Timed t_(c, KID_PROFILE, st);
-    dim3 g2(c->ftx, c->fty, nw);
-    hipLaunchKernelGGL(k_profile, g2, dim3(256), 0, st, k, c->d_wk, c->d_vl, c->d_wt,
+    dim3 g2(c->ftx, c->fty, nw * (k.nvpad / CH));
+    hipLaunchKernelGGL(k_profile, g2, dim3(256), 0, st, k, c->d_wk, c->d_geom,
                        c->d_iunif, c->d_flags, c->d_winflag, (int)c->fz_grid.x, (int)c->fz_grid.y,
                        c->fz_sx, c->fz_sy);
   }
@@ -1336,8 +1313,7 @@ int slamhip_create(const slamhip_desc* d, slamhip_ctx** out) {
   const size_t W = c->wgroup;
   if ((rc = dev_alloc(c, &c->d_wk, W))) return rc;
   if ((rc = dev_alloc(c, &c->d_params, W * NP))) return rc;
-  if ((rc = dev_alloc(c, &c->d_vl, W * 4 * k.nleaf))) return rc;
-  if ((rc = dev_alloc(c, &c->d_wt, W * 4 * k.nleaf))) return rc;
+  if ((rc = dev_alloc(c, &c->d_geom, W * 4 * k.nleaf))) return rc;
   if ((rc = dev_alloc(c, &c->d_iunif, W * k.nv * n * n))) return rc;
   if ((rc = dev_alloc(c, &c->d_iconv, W * k.nv * n * n))) return rc;
   if ((rc = dev_alloc(c, &c->d_partial, W * max_blocks * 3))) return rc;

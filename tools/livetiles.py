@@ -13,3 +13,14 @@ I = fit.engine.iunif(P[0])
 print('walker0 nonzero voxel fraction', np.count_nonzero(I) / I.size)
 nzc = [(I[k] != 0).any() for k in range(I.shape[0])]
 print('channels with emission', sum(nzc), 'of', len(nzc))
+n = I.shape[1]
+def frac(tx, ty):
+    nx, ny = -(-n // tx), -(-n // ty)
+    pad = np.zeros((I.shape[0], ny * ty, nx * tx), bool)
+    pad[:, :n, :n] = I != 0
+    t = pad.reshape(I.shape[0], ny, ty, nx, tx).any(axis=(2, 4))
+    return t.mean()
+for tx, ty in ((32, 8), (16, 16), (64, 64), (64, 8), (64, 1), (8, 8)):
+    print(f'walker0 live fraction of {tx}x{ty} tiles: {frac(tx, ty):.4f}')
+rows = (I != 0).any(axis=2)
+print('live rows fraction', rows.mean())
