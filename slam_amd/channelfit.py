@@ -57,7 +57,8 @@ class ChannelFit(ReadFits):
         self.envelope = envelope
         self.scaling = scaling
         self.progressbar = progressbar
-        self.engine = None
+        self._engine = None
+        self._max_scratch_bytes = 0
         if scaling != 'uniform':
             raise NotImplementedError(
                 f"scaling='{scaling}': only 'uniform' runs on the GPU path")
@@ -176,10 +177,30 @@ class ChannelFit(ReadFits):
         self.xneed = self.xnest[0][self.ineed0:self.ineed1]
         self.yneed = self.ynest[0][self.ineed0:self.ineed1]
 
-        if self.engine is not None:
-            self.engine.close()
-        self.engine = HipLikelihood(self.setup_dict(),
-                                    max_scratch_bytes=max_scratch_bytes)
+        # the constants go to the GPU on first use of the likelihood
+        self.close()
+        self._max_scratch_bytes = max_scratch_bytes
+
+    @property
+    def engine(self):
+        """The GPU-resident likelihood (created on first use; there is no CPU
+        fallback: without libslamhip.so or a GPU this raises SlamhipError)."""
+        if self._engine is None:
+            if not hasattr(self, 'data_valid'):
+                raise RuntimeError('call makegrid() first')
+            self._engine = HipLikelihood(self.setup_dict(),
+                                         max_scratch_bytes=self._max_scratch_bytes)
+        return self._engine
+
+    @engine.setter
+    def engine(self, value):
+        self._engine = value
+
+    def close(self):
+        """Release the GPU context."""
+        if self._engine is not None and hasattr(self._engine, 'close'):
+            self._engine.close()
+        self._engine = None
 
     def setup_dict(self):
         """The constants libslamhip.so needs (slamhip_desc)."""

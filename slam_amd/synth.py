@@ -57,7 +57,7 @@ def make_fit(config='C3', bpa=0.0, seed=12345, N=None, NV=None, beam_px=None,
         truth *= 50 * SIGMA / truth.max()
         rng = np.random.default_rng(seed)
         data = truth + rng.normal(0.0, SIGMA, truth.shape)
-        fit.engine.close()
+        fit.close()
         fit.set_cube(x, y, v, data, bmaj_px * dpix, bmin_px * dpix, bpa, SIGMA)
         fit.makegrid(cubefits=None, **kw)
     return fit

@@ -1,0 +1,179 @@
+"""GPU tests of the product path (`slam_amd.ChannelFit` -> C ABI -> HIP) and
+size-independent properties at BASELINE.json's full sizes, where the oracle is
+too slow to sweep."""
+import contextlib
+import io
+import os
+
+import numpy as np
+import pytest
+
+import _golden
+from oracle import channelfit_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def quiet(fn, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+def product_fit(g):
+    from slam_amd.channelfit import ChannelFit
+    kw = _golden.inputs(g)
+    fit = ChannelFit(disk=kw['disk'], envelope=kw['envelope'], progressbar=False)
+    fit.set_cube(kw['x'], kw['y'], kw['v'], kw['data'], kw['bmaj'], kw['bmin'],
+                 kw['bpa'], kw['sigma'])
+    quiet(fit.makegrid, cubefits=None, pa=kw['pa'], incl=kw['incl'], rmax=kw['rmax'],
+          vlim=kw['vlim'], nlayer=kw['nlayer'], gaussmargin=kw['gaussmargin'],
+          signmajor=kw['signmajor'], signminor=kw['signminor'])
+    return fit
+
+
+def test_channelfit_cubemodel_matches_reference():
+    g = _golden.load('A')
+    fit = product_fit(g)
+    for name in ('generic', 'all_off', 'xyoff_big'):
+        p = dict(zip(fit.paramkeys, g[f'vec_{name}_p']))
+        m = fit.cubemodel(**p)
+        assert _golden.relmax(m, g[f'vec_{name}_model']) < 1e-9
+    m0 = fit.cubemodel(**dict(zip(fit.paramkeys, g['vec_generic_p'])), convolving=False)
+    assert _golden.relmax(m0, g['noconv_model']) < 1e-9
+    fit.close()
+
+
+def test_channelfit_fitting_lnprob_matches_reference(tmp_path):
+    """lnprob handed to the sampler == the reference closure's values."""
+    g = _golden.load('A')
+    gold = np.load(os.path.join(_golden.GOLDEN_DIR, 'channelfit_fitting.npz'))
+    fit = product_fit(g)
+    fixed = {'cs': 0.4, 'Rin': 0, 'Ienv': 0, 'xoff': 0, 'yoff': 0, 'voff': 0,
+             'incloff': 0, 'paoff': 0}
+    quiet(fit.fitting, Mstar_range=[0.1, 1.0], Rc_range=[30, 300], pI_range=[0, 3],
+          h1_range=[0, 0.5], h2_range=[0, 0.5], fixed_params=fixed,
+          filename=str(tmp_path / 'f'),
+          kwargs_emcee_corner={'nwalkers_per_ndim': 4, 'nburnin': 20, 'nsteps': 20, 'seed': 1})
+    np.testing.assert_allclose(fit.lnprob(gold['fit_P']), gold['fit_lnp'], rtol=1e-9)
+    # the short chain must have moved towards the truth (Mstar=0.5, Rc=150) region
+    assert np.isfinite(fit.popt['Mstar']) and os.path.exists(tmp_path / 'f.popt.txt')
+    allfixed = dict(fixed, Mstar=0.5, Rc=150., h1=0.1, h2=0.3, pI=1.)
+    quiet(fit.fitting, fixed_params=allfixed, filename=str(tmp_path / 'h'))
+    np.testing.assert_allclose(fit.chi2r, float(gold['fit_chi2r_allfixed']), rtol=1e-9)
+    fit.close()
+
+
+def test_torch_device_entry_point():
+    import torch
+    g = _golden.load('B')
+    fit = product_fit(g)
+    names = _golden.vectors(g)
+    P = np.array([g[f'vec_{n}_p'] for n in names])
+    ref = np.array([float(g[f'vec_{n}_chi2']) for n in names])
+    out = fit.engine.chi2_batch_torch(torch.as_tensor(P, device='cuda'))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=1e-9)
+    assert np.array_equal(out.cpu().numpy(), fit.engine.chi2_batch(P))
+    fit.close()
+
+
+def test_nan_data_follows_reference():
+    """A NaN in the cube makes np.sum() NaN -> scale NaN -> model NaN ->
+    nansum(...) = 0 in the reference (:486-489, :601)."""
+    from slam_amd import HipLikelihood
+    g = _golden.load('F')
+    kw = _golden.inputs(g)
+    kw['data'] = kw['data'].copy()
+    kw['data'][3, 5, 7] = np.nan
+    s = orc.make_setup(**kw)
+    p = g['vec_deep_p']
+    assert orc.chi2_of(s, p) == 0.0
+    d = dict(s)
+    d['vunit'] = orc.VUNIT
+    with HipLikelihood(d) as eng:
+        assert eng.chi2_batch(p[None])[0] == 0.0
+
+
+def test_negative_scale_clamps_to_zero():
+    """gf < 0 -> scale 0 -> chi2 = sum(d^2)/sigma^2/pixperbeam (:489)."""
+    from slam_amd import HipLikelihood
+    g = _golden.load('F')
+    kw = _golden.inputs(g)
+    kw['data'] = -np.abs(kw['data'])
+    s = orc.make_setup(**kw)
+    d = dict(s)
+    d['vunit'] = orc.VUNIT
+    p = g['vec_deep_p']
+    with HipLikelihood(d) as eng:
+        st = eng.chi2_stats(p[None])
+    assert st['gf'][0] < 0 and st['scale'][0] == 0.0
+    expect = np.sum(kw['data']**2) / s['sigma']**2 / s['pixperbeam']
+    np.testing.assert_allclose(st['chi2'][0], expect, rtol=1e-12)
+    np.testing.assert_allclose(st['chi2'][0], orc.chi2_of(s, p), rtol=1e-12)
+
+
+@pytest.fixture(scope='module')
+def c2():
+    from slam_amd import synth
+    fit = synth.make_fit('C2')
+    yield fit
+    fit.close()
+
+
+def test_c2_vs_oracle(c2):
+    """BASELINE config 2 (256x256x64, fp64 parity): 4 of the 64 walkers against
+    the oracle (0.8 s each), all 64 for internal consistency."""
+    from slam_amd import synth
+    P = synth.walkers(64)
+    got = c2.chi2_batch(P)
+    s = orc.make_setup(c2.x, c2.y, c2.v, c2.data, bmaj=c2.bmaj, bmin=c2.bmin, bpa=c2.bpa,
+                       sigma=c2.sigma, pa=2.0, incl=60.0, rmax=synth.RMAX, signmajor=1,
+                       signminor=1)
+    for i in (0, 17, 40, 63):
+        st = {}
+        model = orc.cubemodel(s, P[i], stages=st)
+        np.testing.assert_allclose(got[i], orc.chi2(s, model), rtol=1e-9)
+        if i == 0:
+            assert _golden.relmax(c2.engine.iunif(P[i]), st['Iunif']) < 1e-12
+            assert _golden.relmax(c2.engine.cubemodel(P[i]), model) < 1e-9
+    # fused hot path vs the unfused cubemodel path, every walker
+    for i in range(0, 64, 7):
+        _, st = c2.engine.cubemodel(P[i], return_stats=True)
+        np.testing.assert_allclose(got[i], st['chi2'], rtol=1e-11)
+
+
+def test_c2_rotated_beam_direct2d():
+    from slam_amd import synth
+    fit = synth.make_fit('C2', bpa=20.0)
+    assert not fit.engine.separable_beam
+    P = synth.walkers(3)
+    got = fit.chi2_batch(P)
+    s = orc.make_setup(fit.x, fit.y, fit.v, fit.data, bmaj=fit.bmaj, bmin=fit.bmin, bpa=fit.bpa,
+                       sigma=fit.sigma, pa=2.0, incl=60.0, rmax=synth.RMAX, signmajor=1,
+                       signminor=1)
+    np.testing.assert_allclose(got[0], orc.chi2_of(s, P[0]), rtol=1e-9)
+    fit.close()
+
+
+def test_c3_properties():
+    """BASELINE config 3 size (512x512x128).  Properties that hold at any size:
+    walkers are independent (order / batch split do not matter, bitwise);
+    the truth parameters beat every random walker; chi2 of the truth is about
+    the number of independent beams; one walker checked against the oracle."""
+    from slam_amd import synth
+    fit = synth.make_fit('C3')
+    P = synth.walkers(96)
+    got = fit.chi2_batch(P)
+    perm = np.random.default_rng(0).permutation(len(P))
+    assert np.array_equal(fit.chi2_batch(P[perm]), got[perm])
+    assert np.array_equal(np.concatenate([fit.chi2_batch(P[:37]), fit.chi2_batch(P[37:])]), got)
+    truth = np.array([[synth.TRUTH[k] for k in fit.paramkeys]])
+    c_truth = fit.chi2_batch(truth)[0]
+    assert c_truth < got.min()
+    nbeam = fit.data_valid.size / fit.pixperbeam
+    assert 0.8 * nbeam < c_truth < 1.2 * nbeam          # noise-only residual
+    s = orc.make_setup(fit.x, fit.y, fit.v, fit.data, bmaj=fit.bmaj, bmin=fit.bmin, bpa=fit.bpa,
+                       sigma=fit.sigma, pa=2.0, incl=60.0, rmax=synth.RMAX, signmajor=1,
+                       signminor=1)
+    np.testing.assert_allclose(got[5], orc.chi2_of(s, P[5]), rtol=1e-9)
+    fit.close()

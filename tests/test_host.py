@@ -1,0 +1,202 @@
+"""Host-side logic on a CPU-only box: makegrid constants, the fit driver's
+free/fixed/log10 bookkeeping, the sampler, FITS I/O.  Where a likelihood value
+is needed the CPU oracle stands in for the GPU engine (tests only)."""
+import contextlib
+import io
+import os
+
+import numpy as np
+import pytest
+
+import _golden
+from oracle import channelfit_oracle as orc
+from slam_amd import fitsio, utils
+from slam_amd.channelfit import ChannelFit, vunit
+
+
+class OracleEngine:
+    """Test double with HipLikelihood's host interface, backed by the oracle."""
+
+    def __init__(self, setup):
+        self.s = setup
+        self.calls = []
+
+    def chi2_batch(self, P):
+        P = np.atleast_2d(P)
+        self.calls.append(len(P))
+        return np.array([orc.chi2_of(self.s, p) for p in P])
+
+    def cubemodel(self, p, convolving=True):
+        return orc.cubemodel(self.s, p, convolving=convolving)
+
+    def close(self):
+        pass
+
+
+def quiet(fn, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+def product_fit(g):
+    kw = _golden.inputs(g)
+    fit = ChannelFit(disk=kw['disk'], envelope=kw['envelope'], progressbar=False)
+    fit.set_cube(kw['x'], kw['y'], kw['v'], kw['data'], kw['bmaj'], kw['bmin'],
+                 kw['bpa'], kw['sigma'])
+    quiet(fit.makegrid, cubefits=None, pa=kw['pa'], incl=kw['incl'], rmax=kw['rmax'],
+          vlim=kw['vlim'], nlayer=kw['nlayer'], gaussmargin=kw['gaussmargin'],
+          signmajor=kw['signmajor'], signminor=kw['signminor'])
+    return fit
+
+
+@pytest.mark.parametrize('name', _golden.CONFIGS)
+def test_makegrid_constants_match_reference(name):
+    g = _golden.load(name)
+    fit = product_fit(g)
+    d = fit.setup_dict()
+    for k in ('Xnest0', 'Ynest0', 'gaussbeam', 'xneed', 'yneed', 'v_valid', 'data_valid'):
+        np.testing.assert_array_equal(d[k], g['setup_' + k], err_msg=k)
+    for k in ('pixperbeam', 'signmajor', 'signminor', 'dv', 'incl0'):
+        assert float(d[k]) == float(g['setup_' + k]), k
+    for k in ('nq1', 'nq3', 'ineed0', 'ineed1', 'nlayer', 'npix'):
+        assert int(d[k]) == int(g['setup_' + k]), k
+    assert d['vunit'] == float(g['setup_vunit']) == vunit
+
+
+def test_no_gpu_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    from slam_amd import SlamhipError
+    fit = product_fit(_golden.load('F'))
+    with pytest.raises(SlamhipError):
+        fit.cubemodel(0.5, 150, 0.4)
+
+
+def test_scaling_variants_refused():
+    with pytest.raises(NotImplementedError):
+        ChannelFit(scaling='mom0clean')
+
+
+@pytest.fixture(scope='module')
+def fitcase():
+    g = _golden.load('A')
+    fit = product_fit(g)
+    fit.engine = OracleEngine(orc.make_setup(**_golden.inputs(g)))
+    return fit, np.load(os.path.join(_golden.GOLDEN_DIR, 'channelfit_fitting.npz'))
+
+
+FIXED = {'cs': 0.4, 'Rin': 0, 'Ienv': 0, 'xoff': 0, 'yoff': 0, 'voff': 0,
+         'incloff': 0, 'paoff': 0}
+RANGES = dict(Mstar_range=[0.1, 1.0], Rc_range=[30, 300], pI_range=[0, 3],
+              h1_range=[0, 0.5], h2_range=[0, 0.5])
+
+
+def test_fitting_bookkeeping_matches_reference(fitcase, tmp_path):
+    """Prior box, labels and the lnprob closure's values equal what the
+    reference's `fitting` hands to its sampler (golden capture)."""
+    fit, gold = fitcase
+    quiet(fit.fitting, **RANGES, fixed_params=FIXED, filename=str(tmp_path / 'f'),
+          kwargs_emcee_corner={'nwalkers_per_ndim': 2, 'nburnin': 2, 'nsteps': 2,
+                               'rangelevel': 0.99, 'seed': 3})
+    np.testing.assert_array_equal(fit.plim, gold['fit_plim'])
+    lnp = fit.lnprob(gold['fit_P'])                    # batched call
+    np.testing.assert_allclose(lnp, gold['fit_lnp'], rtol=1e-12)
+    one = fit.lnprob(gold['fit_P'][0])                 # scalar call, like the reference
+    np.testing.assert_allclose(one, gold['fit_lnp'][0], rtol=1e-12)
+    # result containers and the popt.txt layout
+    assert list(fit.popt) == fit.paramkeys and set(fit.plow) == set(fit.paramkeys)
+    got = open(tmp_path / 'f.popt.txt').read().splitlines()
+    ref = str(gold['fit_popt_txt']).splitlines()
+    assert got[:2] == ref[:2]
+    tab = np.loadtxt(tmp_path / 'f.popt.txt')
+    assert tab.shape == (13, 4)
+    # fixed parameters come back in natural units
+    assert fit.popt['cs'] == 0.4 and fit.popt['Ienv'] == 0.0
+    assert 0.1 < fit.popt['Mstar'] < 1.0 and 30 < fit.popt['Rc'] < 300
+
+
+def test_fitting_batches_half_ensembles(fitcase, tmp_path):
+    fit, _ = fitcase
+    fit.engine.calls.clear()
+    quiet(fit.fitting, **RANGES, fixed_params=FIXED, filename=str(tmp_path / 'g'),
+          kwargs_emcee_corner={'nwalkers_per_ndim': 2, 'nburnin': 1, 'nsteps': 1,
+                               'seed': 5})
+    # ndim = 5 -> 10 walkers: per phase one full-ensemble call + 2 half-ensemble
+    # calls per step (rows outside the prior box are never sent)
+    assert len(fit.engine.calls) == 6
+    assert max(fit.engine.calls) <= 10 and sum(fit.engine.calls) <= 2 * (10 + 10)
+
+
+def test_all_fixed_gives_reduced_chi2(fitcase, tmp_path):
+    fit, gold = fitcase
+    allfixed = dict(FIXED, Mstar=0.5, Rc=150., h1=0.1, h2=0.3, pI=1.)
+    quiet(fit.fitting, fixed_params=allfixed, filename=str(tmp_path / 'h'))
+    np.testing.assert_allclose(fit.chi2r, float(gold['fit_chi2r_allfixed']), rtol=1e-12)
+    assert fit.popt['Mstar'] == 0.5
+
+
+def test_stretch_sampler_recovers_gaussian():
+    rng = np.random.default_rng(0)
+    mu, sig = np.array([1.0, -2.0, 0.5]), np.array([0.5, 1.5, 0.2])
+    seen = []
+
+    def lnp(P):
+        seen.append(P.copy())
+        return -0.5 * np.sum(((P - mu) / sig)**2, axis=1)
+
+    out, sampler = utils.emcee_corner([mu - 6 * sig, mu + 6 * sig], lnp, nwalkers_per_ndim=16,
+                                      nburnin=300, nsteps=600, vectorize=True, seed=1,
+                                      simpleoutput=True, return_sampler=True)
+    pmid, perr = out
+    assert np.all(np.abs(pmid - mu) < 0.15 * sig)
+    assert np.all(np.abs(perr / sig - 1) < 0.15)
+    assert sampler.chain.shape == (48, 600, 3) and sampler.lnprobability.shape == (48, 600)
+    lo, hi = mu - 6 * sig, mu + 6 * sig
+    assert all(np.all((lo < P) & (P < hi)) for P in seen)      # strict box prior
+
+
+def test_emcee_corner_scalar_mode_and_outputs():
+    def lnp(p):
+        assert np.ndim(p) == 1
+        return -0.5 * np.sum(p**2)
+    res = utils.emcee_corner([[-5, -5], [5, 5]], lnp, nwalkers_per_ndim=4, nburnin=20,
+                             nsteps=40, seed=2, simpleoutput=False)
+    popt, plow, pmid, phigh = res
+    assert all(len(a) == 2 for a in res) and np.all(plow <= pmid) and np.all(pmid <= phigh)
+
+
+def test_fits_roundtrip_and_cube_reader(tmp_path):
+    nv, ny, nx = 6, 8, 10
+    rng = np.random.default_rng(4)
+    cube = rng.normal(size=(nv, ny, nx))
+    h = {'CTYPE1': 'RA---SIN', 'CRVAL1': 69.9744917, 'CRPIX1': 6.0, 'CDELT1': -1e-5,
+         'CTYPE2': 'DEC--SIN', 'CRVAL2': 26.0526194, 'CRPIX2': 5.0, 'CDELT2': 1e-5,
+         'CTYPE3': 'FREQ', 'CRVAL3': 2.30538e11, 'CRPIX3': 1.0, 'CDELT3': -1.0e5,
+         'CUNIT3': 'Hz', 'RESTFRQ': 2.30538e11, 'BMAJ': 4e-5, 'BMIN': 3e-5, 'BPA': 12.5,
+         'BUNIT': 'Jy/beam', 'OBJECT': "it's"}
+    path = str(tmp_path / 'cube.fits')
+    fitsio.write_cube(path, cube, h)
+    d, hh = fitsio.read_primary(path)
+    np.testing.assert_array_equal(d, cube)
+    assert hh['NAXIS1'] == nx and hh['NAXIS3'] == nv and hh['BPA'] == 12.5
+    assert hh['OBJECT'] == "it's" and hh['CUNIT3'] == 'Hz'
+
+    r = utils.ReadFits()
+    out = quiet(r.read_cubefits, path, center='04h39m53.878s +26d03m09.43s', dist=140,
+                vsys=5.9, sigma=1e-3)
+    # offsets of the map centre from `center` (small-angle check of the sky-offset frame)
+    ra, dec = utils.parse_center('04h39m53.878s +26d03m09.43s')
+    cx = (ra - h['CRVAL1']) * np.cos(np.radians(h['CRVAL2']))
+    cy = dec - h['CRVAL2']
+    x_ref = ((np.arange(nx) - 5) * h['CDELT1'] - cx) * 3600 * 140
+    y_ref = ((np.arange(ny) - 4) * h['CDELT2'] - cy) * 3600 * 140
+    np.testing.assert_allclose(out['x'], x_ref, atol=2e-3)
+    np.testing.assert_allclose(out['y'], y_ref, atol=2e-3)
+    v_ref = (1 - (h['CRVAL3'] + np.arange(nv) * h['CDELT3']) / h['RESTFRQ']) * 299792.458 - 5.9
+    np.testing.assert_allclose(out['v'], v_ref, rtol=1e-12)
+    assert r.bmaj == pytest.approx(4e-5 * 3600 * 140) and r.bpa == 12.5
+    assert r.dv == pytest.approx(v_ref[1] - v_ref[0])
+    # cropping keeps the pixels nearest to the limits (utils.py:249-258)
+    out = quiet(r.read_cubefits, path, dist=140, xmin=-10, xmax=10, ymin=-10, ymax=10, sigma=1e-3)
+    assert out['data'].shape[0] == nv and out['x'].max() <= 12 and out['x'].min() >= -12
