@@ -626,95 +626,365 @@ k_conv_sep(FitK g, const double* __restrict__ in, double* __restrict__ out,
     }
 }
 
+// One live conv window, everything k_conv_chi2 needs to start loading at once.
+struct __attribute__((aligned(16))) WinDesc {
+  int e;                         // window id: (walker*nv + channel)*wnx*wny + by*wnx + bx
+  int ixa, ixb, jya, jyb;        // observed pixel ranges whose cells it owns
+  int pad[3];
+  unsigned long long occ[FLAG_MAX / 64];   // occupied 32x8 input tiles under the window
+};
+
 // k_compact: list of conv windows that contain emission (order irrelevant:
-// every window writes its partial sums to its own slot).
+// every window writes its partial sums to its own slot), each with the
+// occupancy bitmap of the input tiles under it.
 __global__ void __launch_bounds__(256)
-k_compact(const unsigned char* __restrict__ winflag, int total, int* __restrict__ list,
-          int* __restrict__ count) {
+k_compact(FitK g, const unsigned char* __restrict__ winflag, int total,
+          const unsigned char* __restrict__ flags, int ftx, int fty,
+          const int* __restrict__ tile_ix, const int* __restrict__ tile_jy,
+          int wnx, int wny, int sx, int sy, int ty,
+          WinDesc* __restrict__ list, int* __restrict__ count) {
   const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e < total && winflag[e]) list[atomicAdd(count, 1)] = e;
+  if (e >= total || !winflag[e]) return;
+  const int n = g.nneed;
+  const int z = e / (wnx * wny), tl = e - z * (wnx * wny);
+  const int tby = tl / wnx, tbx = tl - tby * wnx;
+  const int wi = z / g.nv;
+  const int wx0 = tbx * sx - g.ngauss, wy0 = tby * sy - g.ngauss;
+  const int vcols = CONV_TX + g.kbeam - 1, vrows = ty + g.kbeam - 1;
+  const int ftx0 = max(wx0, 0) / PT_X, fty0 = max(wy0, 0) / PT_Y;
+  const int fnx = min(wx0 + vcols - 1, n - 1) / PT_X - ftx0 + 1;
+  const int fny = min(wy0 + vrows - 1, n - 1) / PT_Y - fty0 + 1;
+  WinDesc d;
+  d.e = e;
+  d.ixa = tile_ix[((long long)wi * wnx + tbx) * 2];
+  d.ixb = tile_ix[((long long)wi * wnx + tbx) * 2 + 1];
+  d.jya = tile_jy[((long long)wi * wny + tby) * 2];
+  d.jyb = tile_jy[((long long)wi * wny + tby) * 2 + 1];
+  d.pad[0] = d.pad[1] = d.pad[2] = 0;
+#pragma unroll
+  for (int q = 0; q < FLAG_MAX / 64; ++q) d.occ[q] = 0ull;
+  const unsigned char* fl = flags + (long long)z * ftx * fty;
+  for (int fy = 0; fy < fny; ++fy)
+    for (int fx = 0; fx < fnx; ++fx) {
+      const int q = fy * fnx + fx;
+      if (fl[(long long)(fty0 + fy) * ftx + ftx0 + fx]) d.occ[q >> 6] |= 1ull << (q & 63);
+    }
+  list[atomicAdd(count, 1)] = d;
 }
 
-// k_conv_chi2: the hot-path form.  Convolves a tile, keeps it in LDS, regrids
-// it bilinearly onto the observed pixels whose interpolation cell it owns
-// (:475-483) and reduces sum(I*d), sum(I*I) for get_scale (:485-490): wave
-// shuffles, then a block reduction.  The convolved cube never reaches HBM, and
-// an all-zero tile costs neither FLOPs nor a read of the data cube.
-// Tiles overlap by one node: tile (bx, by) owns cells [x0, x0+TX-1) x
+// k_conv_chi2: the hot-path form.  Persistent 512-thread workgroups walk the
+// list of windows that contain emission.  Per window: stage only the occupied
+// 32x8 input tiles into a zeroed LDS tile, separable row pass over the rows
+// that hold emission (results in registers across the barrier), column pass
+// (tap blocks over empty rows skipped), keep the convolved 64xTY nodes in LDS,
+// regrid them bilinearly onto the observed pixels whose interpolation cell the
+// window owns (:475-483) and reduce sum(I*d), sum(I*I) for get_scale
+// (:485-490) with wave shuffles, then a block reduction.  The convolved cube
+// never reaches HBM; empty sky costs neither FLOPs nor a read of the data cube.
+// Windows overlap by one node: window (bx, by) owns cells [x0, x0+TX-1) x
 // [y0, y0+TY-1) with x0 = bx*(TX-1), y0 = by*(TY-1).
+constexpr int CV_NT = 512;                   // threads per workgroup
+constexpr int CV_NW = CV_NT / 64;            // waves
+
 template <int TY, int MAXR>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(CV_NT, 4)
 k_conv_chi2(FitK g, const double* __restrict__ iunif,
             const int* __restrict__ cellx, const double* __restrict__ fracx,
             const int* __restrict__ celly, const double* __restrict__ fracy,
-            const int* __restrict__ tile_ix, const int* __restrict__ tile_jy,
-            const unsigned char* __restrict__ flags, int ftx, int fty,
-            const int* __restrict__ list, const int* __restrict__ count, int wnx, int wny,
+            const WinDesc* __restrict__ list, const int* __restrict__ count, int wnx, int wny,
             double* __restrict__ partial, int kpad) {
   extern __shared__ double lds[];
-  constexpr int TX = CONV_TX, R = CONV_R, PC = TX + 1;
-  __shared__ double sg[4], sf[4];
-  const int n = g.nneed;
+  constexpr int TX = CONV_TX, R = CONV_R, PC = TX + 1, P2 = TX + 1;
+  constexpr int NRQ = (TY - 1 + CV_NW - 1) / CV_NW;         // regrid rows per wave
+  constexpr int NSB = 2;                                    // staged tiles per wave held in registers
+  __shared__ unsigned char s_rowlist[256];
+  __shared__ unsigned long long s_rowmask[2][4];            // tile rows with emission (<= 256)
+  __shared__ double sg[CV_NW], sf[CV_NW];
+  const int K = g.kbeam, ng = g.ngauss, n = g.nneed;
+  const int rows = TY + kpad - 1, cols = TX + kpad - 1;
+  const int P = cols | 1;
+  const int vrows = TY + K - 1, vcols = TX + K - 1;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  double* wxl = lds + rows * P;                             // flipped taps, zero padded
+  double* wyl = wxl + kpad;
+  for (int e = tid; e < kpad; e += CV_NT) { wxl[e] = g.gx_pad[e]; wyl[e] = g.gy_pad[e]; }
+  if (tid < 8) s_rowmask[tid >> 2][tid & 3] = 0ull;
+  __syncthreads();
   const int nlive = *count;
-  // persistent blocks stride over the live-window list; every wave reaches the
-  // loop exit after ceil(nlive / gridDim.x) iterations
-  for (int it = blockIdx.x; it < nlive; it += gridDim.x) {
-  const int e = list[it];
-  const int z = e / (wnx * wny), tl = e - z * (wnx * wny);
-  const int tby = tl / wnx, tbx = tl - tby * wnx;
-  const int wi = z / g.nv, k = z - wi * g.nv;
-  const double* src = iunif + (long long)z * n * n;
-  const int x0 = tbx * (TX - 1), y0 = tby * (TY - 1);
-  const long long blk = e;
-  ConvAcc<TY> acc;
-  const unsigned char* fl = flags + (long long)z * ftx * fty;
-  if (!conv_tile<TY, MAXR>(g, src, fl, ftx, fty, x0, y0, kpad, lds, acc)) {
-    if (tid == 0) { partial[3 * blk] = 0.0; partial[3 * blk + 1] = 0.0; partial[3 * blk + 2] = 0.0; }
-    __syncthreads();
-    continue;
-  }
-  __syncthreads();                         // column pass done reading LDS
-#pragma unroll
-  for (int q = 0; q < ConvAcc<TY>::NYB; ++q)
-#pragma unroll
-    for (int r = 0; r < R; ++r) lds[((wv + 4 * q) * R + r) * PC + lane] = acc.v[q][r];
+  constexpr int DW = sizeof(WinDesc) / 4;                   // descriptor dwords
+  __shared__ unsigned s_desc[2][DW];
+  if (tid < DW && (int)blockIdx.x < nlive)
+    s_desc[0][tid] = reinterpret_cast<const unsigned*>(&list[blockIdx.x])[tid];
   __syncthreads();
-  const int* tix = tile_ix + ((long long)wi * wnx + tbx) * 2;
-  const int* tjy = tile_jy + ((long long)wi * wny + tby) * 2;
-  const int ixa = tix[0], ixb = tix[1], jya = tjy[0], jyb = tjy[1];
-  const int* cx = cellx + (long long)wi * g.nx;
-  const int* cy = celly + (long long)wi * g.ny;
-  const double* fx = fracx + (long long)wi * g.nx;
-  const double* fy = fracy + (long long)wi * g.ny;
-  const double* dat = g.data + (long long)k * g.ny * g.nx;
-  double gf = 0.0, ff = 0.0;
-  for (int ix = ixa + lane; ix < ixb; ix += 64) {
-    const int i1 = cx[ix] - x0;
-    const double t1 = fx[ix];
-    if (i1 < 0 || i1 >= TX - 1) continue;                  // owned by another tile
-    for (int jy = jya + wv; jy < jyb; jy += 4) {
-      const int i0 = cy[jy] - y0;                          // wave-uniform
-      if (i0 < 0 || i0 >= TY - 1) continue;
-      const double t0 = fy[jy];
-      const double* c = lds + i0 * PC + i1;
-      const double v00 = c[0], v01 = c[1], v10 = c[PC], v11 = c[PC + 1];
-      const double val = v00 * (1 - t0) * (1 - t1) + v01 * (1 - t0) * t1 +
-                         v10 * t0 * (1 - t1) + v11 * t0 * t1;
-      gf = fma(val, dat[(long long)jy * g.nx + ix], gf);
-      ff = fma(val, val, ff);
+  // every wave reaches the loop exit after ceil(nlive / gridDim.x) iterations
+  int par = 0;
+  for (int it = blockIdx.x; it < nlive; it += gridDim.x, par ^= 1) {
+    // next window's descriptor: in flight during this window, parked in LDS at its end
+    unsigned nextw = 0;
+    if (tid < DW && it + (int)gridDim.x < nlive)
+      nextw = reinterpret_cast<const unsigned*>(&list[it + gridDim.x])[tid];
+    const unsigned long long* occ = reinterpret_cast<const unsigned long long*>(&s_desc[par][8]);
+    const int e = (int)s_desc[par][0];
+    const int z = e / (wnx * wny), tl = e - z * (wnx * wny);
+    const int tby = tl / wnx, tbx = tl - tby * wnx;
+    const int wi = z / g.nv, k = z - wi * g.nv;
+    const double* src = iunif + (long long)z * n * n;
+    const int x0 = tbx * (TX - 1), y0 = tby * (TY - 1);
+    const int wx0 = x0 - ng, wy0 = y0 - ng;                 // window origin (image coords)
+    const int ftx0 = max(wx0, 0) / PT_X, fty0 = max(wy0, 0) / PT_Y;
+    const int fnx = min(wx0 + vcols - 1, n - 1) / PT_X - ftx0 + 1;
+    const int fny = min(wy0 + vrows - 1, n - 1) / PT_Y - fty0 + 1;
+
+    // -- 0. issue every global load of this window now: the occupied input
+    //       tiles (NSB per wave in registers) and what the regrid needs
+    double sv[NSB][4];
+    int srr[NSB], scc[NSB];
+    {
+      int seen = 0, slot = 0;
+#pragma unroll
+      for (int u = 0; u < NSB; ++u) { srr[u] = -1; scc[u] = 0; sv[u][0] = sv[u][1] = sv[u][2] = sv[u][3] = 0.0; }
+      for (int qw = 0; qw < FLAG_MAX / 64 && slot < NSB; ++qw) {
+        unsigned long long m = occ[qw];
+        while (m && slot < NSB) {
+          const int q = qw * 64 + __builtin_ctzll(m);
+          m &= m - 1;
+          if ((seen++ & (CV_NW - 1)) != wv) continue;
+          const int fyy = q / fnx, fxx = q - fyy * fnx;
+          const int gy = (fty0 + fyy) * PT_Y + (lane >> 3);
+          const int gx0 = (ftx0 + fxx) * PT_X + (lane & 7) * 4;
+          const int rr = gy - wy0;
+          const bool rowok = gy < n && rr >= 0 && rr < vrows;
+#pragma unroll
+          for (int u = 0; u < NSB; ++u)
+            if (u == slot) {
+              srr[u] = rowok ? rr : -1;
+              scc[u] = gx0 - wx0;
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                const int gx = gx0 + j, cc = gx - wx0;
+                sv[u][j] = (rowok && gx < n && cc >= 0 && cc < vcols) ? src[(long long)gy * n + gx] : 0.0;
+              }
+            }
+          ++slot;
+        }
+      }
     }
-  }
-  gf = wave_sum(gf);
-  ff = wave_sum(ff);
-  if (lane == 0) { sg[wv] = gf; sf[wv] = ff; }
-  __syncthreads();
-  if (tid == 0) {
-    partial[3 * blk] = (sg[0] + sg[1]) + (sg[2] + sg[3]);
-    partial[3 * blk + 1] = (sf[0] + sf[1]) + (sf[2] + sf[3]);
-    partial[3 * blk + 2] = 1.0;                            // tile was not empty
-  }
-  __syncthreads();                         // LDS is restaged by the next window
+    const int* cy = celly + (long long)wi * g.ny;
+    const double* fy = fracy + (long long)wi * g.ny;
+    const double* dat = g.data + (long long)k * g.ny * g.nx;
+    const int ixa = (int)s_desc[par][1], ixb = (int)s_desc[par][2], jya = (int)s_desc[par][3],
+              jyb = (int)s_desc[par][4];
+    const int ix = ixa + lane;
+    int i1 = -1;
+    double t1 = 0.0;
+    double dv[NRQ];
+    if (ix < ixb) {
+      i1 = cellx[(long long)wi * g.nx + ix] - x0;
+      t1 = fracx[(long long)wi * g.nx + ix];
+    }
+#pragma unroll
+    for (int q = 0; q < NRQ; ++q) {
+      const int jy = jya + wv + CV_NW * q;
+      dv[q] = (ix < ixb && jy < jyb) ? dat[(long long)jy * g.nx + ix] : 0.0;
+    }
+    const bool xown = i1 >= 0 && i1 < TX - 1;               // else owned by another window
+
+    // -- 1. zero the LDS tile; rows that hold emission
+    for (int q = tid; q < rows * P; q += CV_NT) lds[q] = 0.0;
+    if (tid < fny) {
+      unsigned long long any = 0ull;
+      for (int fxx = 0; fxx < fnx; ++fxx) {
+        const int q = tid * fnx + fxx;
+        any |= (occ[q >> 6] >> (q & 63)) & 1ull;
+      }
+      if (any) {
+        const int r0 = max((fty0 + tid) * PT_Y - wy0, 0);
+        const int r1 = min((fty0 + tid + 1) * PT_Y - wy0, vrows);   // exclusive
+        for (int r = r0; r < r1; ++r) atomicOr(&s_rowmask[par][r >> 6], 1ull << (r & 63));
+      }
+    }
+    __syncthreads();
+
+    // -- 2. list of rows with emission; staged tiles into LDS
+    if (tid < 4) s_rowmask[par ^ 1][tid] = 0ull;
+    const unsigned long long m0 = s_rowmask[par][0], m1 = s_rowmask[par][1],
+                             m2 = s_rowmask[par][2], m3 = s_rowmask[par][3];
+    const int nlr = __popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3);
+    if (tid < rows) {
+      const unsigned long long mw = tid < 64 ? m0 : tid < 128 ? m1 : tid < 192 ? m2 : m3;
+      if ((mw >> (tid & 63)) & 1ull) {
+        int pos = __popcll(mw & ((1ull << (tid & 63)) - 1ull));
+        if (tid >= 64) pos += __popcll(m0);
+        if (tid >= 128) pos += __popcll(m1);
+        if (tid >= 192) pos += __popcll(m2);
+        s_rowlist[pos] = (unsigned char)tid;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < NSB; ++u)
+      if (srr[u] >= 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int cc = scc[u] + j;
+          if (cc >= 0 && cc < vcols) lds[srr[u] * P + cc] = sv[u][j];
+        }
+      }
+    {
+      // occupied tiles beyond NSB per wave (crowded windows): load and store directly
+      int seen = 0, mine = 0;
+      for (int qw = 0; qw < FLAG_MAX / 64; ++qw) {
+        unsigned long long m = occ[qw];
+        while (m) {
+          const int q = qw * 64 + __builtin_ctzll(m);
+          m &= m - 1;
+          if ((seen++ & (CV_NW - 1)) != wv) continue;
+          if (mine++ < NSB) continue;
+          const int fyy = q / fnx, fxx = q - fyy * fnx;
+          const int gy = (fty0 + fyy) * PT_Y + (lane >> 3);
+          const int gx0 = (ftx0 + fxx) * PT_X + (lane & 7) * 4;
+          const int rr = gy - wy0;
+          if (gy < n && rr >= 0 && rr < vrows) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int gx = gx0 + j, cc = gx - wx0;
+              if (gx < n && cc >= 0 && cc < vcols) lds[rr * P + cc] = src[(long long)gy * n + gx];
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+
+    // -- 3. row pass over the rows with emission: tmp[row][x] = sum_u gxf[u] tile[row][x+u]
+    const int nitem = nlr * (TX / R);
+    double res[MAXR][R];
+#pragma unroll
+    for (int q = 0; q < MAXR; ++q) {
+      const int item = q * CV_NT + tid;
+#pragma unroll
+      for (int r = 0; r < R; ++r) res[q][r] = 0.0;
+      if (item < nitem) {
+        const int xb = item / nlr, rr = s_rowlist[item - xb * nlr];
+        const double* row = lds + rr * P + xb * R;
+        double win[R];
+#pragma unroll
+        for (int r = 0; r < R - 1; ++r) win[r] = row[r];
+        for (int u0 = 0; u0 < kpad; u0 += R) {
+#pragma unroll
+          for (int qq = 0; qq < R; ++qq) {
+            win[(qq + R - 1) % R] = row[u0 + qq + R - 1];
+            const double wgt = wxl[u0 + qq];
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+              res[q][r] = fma(wgt, win[(r + qq) % R], res[q][r]);
+          }
+        }
+      }
+    }
+    __syncthreads();
+    // rows without emission convolve to zero; the others come from registers
+    for (int q = tid; q < rows * (TX / R); q += CV_NT) {
+      const int rr = q / (TX / R), xb = q - rr * (TX / R);
+      const unsigned long long mw = rr < 64 ? m0 : rr < 128 ? m1 : rr < 192 ? m2 : m3;
+      if (!((mw >> (rr & 63)) & 1ull)) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) lds[rr * P2 + xb * R + r] = 0.0;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < MAXR; ++q) {
+      const int item = q * CV_NT + tid;
+      if (item < nitem) {
+        const int xb = item / nlr, rr = s_rowlist[item - xb * nlr];
+#pragma unroll
+        for (int r = 0; r < R; ++r) lds[rr * P2 + xb * R + r] = res[q][r];
+      }
+    }
+    __syncthreads();
+
+    // -- 4. column pass: out[y][x] = sum_u gyf[u] tmp[y+u][x]; lanes <-> x, waves <-> y blocks
+    double acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = 0.0;
+    if (wv < TY / R) {
+      const double* col = lds + (wv * R) * P2 + lane;
+      for (int u0 = 0; u0 < kpad; u0 += R) {
+        // rows wv*R+u0 .. +2R-2 feed this tap block: skip it if none holds emission
+        const int ra = wv * R + u0;
+        unsigned long long bits = 0ull;
+        {
+          const int w0 = ra >> 6, sh = ra & 63;
+          const unsigned long long lo = w0 == 0 ? m0 : w0 == 1 ? m1 : w0 == 2 ? m2 : m3;
+          const unsigned long long hi = w0 == 0 ? m1 : w0 == 1 ? m2 : w0 == 2 ? m3 : 0ull;
+          bits = (lo >> sh) | (sh ? (hi << (64 - sh)) : 0ull);
+        }
+        if (!(bits & ((1ull << (2 * R - 1)) - 1ull))) continue;
+        double win[2 * R - 1];
+#pragma unroll
+        for (int r = 0; r < 2 * R - 1; ++r) win[r] = col[(u0 + r) * P2];
+#pragma unroll
+        for (int qq = 0; qq < R; ++qq) {
+          const double wgt = wyl[u0 + qq];
+#pragma unroll
+          for (int r = 0; r < R; ++r) acc[r] = fma(wgt, win[r + qq], acc[r]);
+        }
+      }
+    }
+    __syncthreads();                                        // column pass done reading LDS
+    if (wv < TY / R) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) lds[(wv * R + r) * PC + lane] = acc[r];
+    }
+    __syncthreads();
+
+    // -- 5. regrid + chi-square sums from the LDS tile
+    double gf = 0.0, ff = 0.0;
+#pragma unroll
+    for (int q = 0; q < NRQ; ++q) {
+      const int jy = jya + wv + CV_NW * q;
+      if (jy < jyb) {
+        const int i0 = cy[jy] - y0;                         // wave-uniform
+        if (xown && i0 >= 0 && i0 < TY - 1) {
+          const double t0 = fy[jy];
+          const double* c = lds + i0 * PC + i1;
+          const double v00 = c[0], v01 = c[1], v10 = c[PC], v11 = c[PC + 1];
+          const double val = v00 * (1 - t0) * (1 - t1) + v01 * (1 - t0) * t1 +
+                             v10 * t0 * (1 - t1) + v11 * t0 * t1;
+          gf = fma(val, dv[q], gf);
+          ff = fma(val, val, ff);
+        }
+      }
+    }
+    // (only if the observed grid is finer than the model grid) further columns / rows
+    for (int ix2 = ix; ix2 < ixb; ix2 += 64) {
+      const int i1b = cellx[(long long)wi * g.nx + ix2] - x0;
+      if (i1b < 0 || i1b >= TX - 1) continue;
+      const double t1b = fracx[(long long)wi * g.nx + ix2];
+      for (int jy = jya + wv + (ix2 == ix ? CV_NW * NRQ : 0); jy < jyb; jy += CV_NW) {
+        const int i0 = cy[jy] - y0;
+        if (i0 < 0 || i0 >= TY - 1) continue;
+        const double t0 = fy[jy];
+        const double* c = lds + i0 * PC + i1b;
+        const double val = c[0] * (1 - t0) * (1 - t1b) + c[1] * (1 - t0) * t1b +
+                           c[PC] * t0 * (1 - t1b) + c[PC + 1] * t0 * t1b;
+        gf = fma(val, dat[(long long)jy * g.nx + ix2], gf);
+        ff = fma(val, val, ff);
+      }
+    }
+    gf = wave_sum(gf);
+    ff = wave_sum(ff);
+    if (lane == 0) { sg[wv] = gf; sf[wv] = ff; }
+    if (tid < DW) s_desc[par ^ 1][tid] = nextw;
+    __syncthreads();
+    if (tid == 0) {
+      double a = 0.0, b2 = 0.0;
+#pragma unroll
+      for (int q = 0; q < CV_NW; ++q) { a += sg[q]; b2 += sf[q]; }
+      partial[3 * (long long)e] = a;
+      partial[3 * (long long)e + 1] = b2;
+      partial[3 * (long long)e + 2] = 1.0;                  // window was convolved
+    }
+    // the next window's first barrier orders its LDS writes after these reads
   }
 }
 
@@ -916,7 +1186,7 @@ struct slamhip_ctx {
   unsigned char* d_flags = nullptr;   // [walker][nv][fty][ftx] occupancy of Iunif tiles
   int ftx = 1, fty = 1;
   unsigned char* d_winflag = nullptr; // [walker][nv][wny][wnx] conv windows with emission (+ counter)
-  int* d_livelist = nullptr;
+  WinDesc* d_livelist = nullptr;
   int* d_livecount = nullptr;
   int persist_blocks = 1;
   int* d_tile_ix = nullptr;
@@ -930,7 +1200,7 @@ struct slamhip_ctx {
   int conv_mode = 0;
   int kpad = 0;
   int sep_variant = 0;     // 0: <64,3>  1: <64,5>  2: <32,4>  -1: none fits
-  size_t sep_lds = 0, c2d_lds = 0;
+  size_t sep_lds = 0, c2d_lds = 0, fz_lds = 0;
   hipStream_t stream = nullptr;
   // optional per-kernel HIP-event timing (slamhip_profile_begin/_end)
   bool profiling = false;
@@ -1112,22 +1382,23 @@ int run_group(slamhip_ctx* c, const double* d_params, int nw, double* d_chi2,
     const int nwin = (int)(c->fz_grid.x * c->fz_grid.y * c->fz_grid.z) * nw;
     {
       Timed t_(c, KID_COMPACT, st);
-      hipLaunchKernelGGL(k_compact, dim3((nwin + 255) / 256), dim3(256), 0, st, c->d_winflag, nwin,
+      hipLaunchKernelGGL(k_compact, dim3((nwin + 255) / 256), dim3(256), 0, st, c->k, c->d_winflag, nwin,
+                         c->d_flags, c->ftx, c->fty, c->d_tile_ix, c->d_tile_jy,
+                         (int)c->fz_grid.x, (int)c->fz_grid.y, c->fz_sx, c->fz_sy, c->fz_sy + 1,
                          c->d_livelist, c->d_livecount);
     }
     {
       Timed t_(c, KID_CONV, st);
       dim3 gz(c->persist_blocks, 1, 1);
 #define SLAM_FUSED(TY_, MR_)                                                              \
-      hipLaunchKernelGGL((k_conv_chi2<TY_, MR_>), gz, dim3(256), c->sep_lds, st, c->k,    \
+      hipLaunchKernelGGL((k_conv_chi2<TY_, MR_>), gz, dim3(CV_NT), c->fz_lds, st, c->k,   \
                          c->d_iunif, c->d_cellx, c->d_fracx, c->d_celly, c->d_fracy,       \
-                         c->d_tile_ix, c->d_tile_jy, c->d_flags, c->ftx, c->fty,           \
                          c->d_livelist, c->d_livecount, (int)c->fz_grid.x, (int)c->fz_grid.y, \
                          c->d_partial, c->kpad)
       switch (c->sep_variant) {
-        case 0: SLAM_FUSED(64, 3); break;
-        case 1: SLAM_FUSED(64, 5); break;
-        default: SLAM_FUSED(32, 4); break;
+        case 0: SLAM_FUSED(64, 2); break;
+        case 1: SLAM_FUSED(64, 3); break;
+        default: SLAM_FUSED(32, 2); break;
       }
 #undef SLAM_FUSED
     }
@@ -1263,11 +1534,14 @@ int slamhip_create(const slamhip_desc* d, slamhip_ctx** out) {
     const void* fn = c->sep_variant == 0 ? (const void*)k_conv_sep<64, 3>
                    : c->sep_variant == 1 ? (const void*)k_conv_sep<64, 5>
                                          : (const void*)k_conv_sep<32, 4>;
-    const void* fz = c->sep_variant == 0 ? (const void*)k_conv_chi2<64, 3>
-                   : c->sep_variant == 1 ? (const void*)k_conv_chi2<64, 5>
-                                         : (const void*)k_conv_chi2<32, 4>;
     HIP_TRY(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->sep_lds));
-    HIP_TRY(c, hipFuncSetAttribute(fz, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->sep_lds));
+  }
+  c->fz_lds = c->sep_lds + 2 * (size_t)c->kpad * sizeof(double);
+  if (c->fz_lds > 48 * 1024 && c->sep_variant >= 0) {
+    const void* fz = c->sep_variant == 0 ? (const void*)k_conv_chi2<64, 2>
+                   : c->sep_variant == 1 ? (const void*)k_conv_chi2<64, 3>
+                                         : (const void*)k_conv_chi2<32, 2>;
+    HIP_TRY(c, hipFuncSetAttribute(fz, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->fz_lds));
   }
   c->fused = c->separable && c->sep_variant >= 0;
   {
@@ -1339,7 +1613,7 @@ int slamhip_create(const slamhip_desc* d, slamhip_ctx** out) {
     if ((rc = dev_alloc(c, &c->d_livecount, 64))) return rc;
     hipDeviceProp_t prop;
     HIP_TRY(c, hipGetDeviceProperties(&prop, c->device));
-    const int per_cu = std::max(1, (int)((160 * 1024) / std::max<size_t>(c->sep_lds + 1024, 1)));
+    const int per_cu = std::max(1, (int)((160 * 1024) / std::max<size_t>(c->fz_lds + 2048, 1)));
     c->persist_blocks = prop.multiProcessorCount * std::min(per_cu, 8);
   }
   if ((rc = dev_alloc(c, &c->d_tile_ix, W * c->fz_grid.x * 2))) return rc;
