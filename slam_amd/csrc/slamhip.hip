@@ -40,6 +40,7 @@ constexpr int CH = 32;                       // channels accumulated in register
 constexpr int CONV_TX = 64;                  // conv tile width (= one wave)
 constexpr int CONV_R = 8;                    // outputs per thread along the tap axis
 constexpr int RED_THREADS = 256;
+constexpr unsigned LEAF_PAD = 0xffffffffu;    // slot without a sample
 constexpr int FLAG_MAX = 512;                // occupancy bytes one conv window may span
 
 // ---------------------------------------------------------------------------
@@ -50,6 +51,7 @@ struct FitK {
   int disk, envelope;
   int nvpad;            // nv rounded up to a multiple of CH
   long long nleaf;      // nested-grid samples that survive the layer merge
+  long long nslot;      // sample slots: per 32x8 tile, [sample rank][pixel], padded
   double dv, sigma, pixperbeam, incl0, signmajor, signminor, vunit;
   double ssq_data;      // sum(data_valid^2), fixed per fit
   int data_has_nan;
@@ -66,8 +68,9 @@ struct FitK {
   const double* beam;       // [K][K]
   const double* gx_pad;     // separable factors, flipped + zero padded
   const double* gy_pad;
-  const unsigned* leaf;     // packed (layer:4 | row:14 | col:14)
-  const int* leaf_off;      // [nneed*nneed + 1] CSR offsets, pixel-major
+  const unsigned* leaf;     // [nslot] packed (layer:4 | row:14 | col:14), LEAF_PAD = none
+  const int* tile_goff;     // [tiles] first slot of each 32x8 pixel tile
+  const int* tile_nl;       // [tiles] sample ranks in the tile (max samples per pixel)
 };
 
 // Per-walker constants written by k_prep.
@@ -280,15 +283,21 @@ __device__ inline Surf surface_eval(const FitK& g, const WalkerK& w, int s,
 // k_surface: thread per (walker, surviving sample).  Writes, per live surface,
 //   vl = vlos*sqrt(Mstar)          (1e300 where the reference has NaN)
 //   wt = intensity weight * layer-merge weight 4^-layer
-// as one {vl, wt} pair laid out [walker][surface][sample] so k_profile reads them
-// coalesced, 16 B per lane.
+// as one {vl, wt} pair laid out [walker][surface][slot]; slots are ordered per
+// 32x8 pixel tile as [sample rank][pixel] so k_profile's lanes (= pixels) read
+// consecutive 16-B entries for every rank.
 __global__ void __launch_bounds__(256)
 k_surface(FitK g, const WalkerK* __restrict__ wk, double2* __restrict__ geom) {
-  const long long leaf = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (leaf >= g.nleaf) return;
+  const long long leaf = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // slot
+  if (leaf >= g.nslot) return;
   const int wi = blockIdx.z;
   const WalkerK& w = wk[wi];
   const unsigned code = g.leaf[leaf];
+  if (code == LEAF_PAD) {                                  // keeps k_profile's loads uniform
+    for (int s = 0; s < wk[blockIdx.z].nsurf; ++s)
+      geom[((long long)blockIdx.z * 4 + s) * g.nslot + leaf] = make_double2(VL_MASKED, 0.0);
+    return;
+  }
   const int l = code >> 28, j = (code >> 14) & 0x3fff, i = code & 0x3fff;
   const long long idx = ((long long)l * g.npix + j) * g.npix + i;
   const double X0 = g.Xnest0[idx], Y0 = g.Ynest0[idx];
@@ -309,7 +318,7 @@ k_surface(FitK g, const WalkerK* __restrict__ wk, double2* __restrict__ geom) {
       if (fabs(wt) > 1.79769313486231570815e308)           // nan_to_num(inf) :468
         wt = copysign(1.79769313486231570815e308, wt);
     }
-    geom[((long long)wi * 4 + s) * g.nleaf + leaf] = make_double2(vl, wt);
+    geom[((long long)wi * 4 + s) * g.nslot + leaf] = make_double2(vl, wt);
   }
 }
 
@@ -380,67 +389,79 @@ k_profile(FitK g, const WalkerK* __restrict__ wk, const double2* __restrict__ ge
   const int y = blockIdx.y * PT_Y + tid / PT_X;
   const bool inb = x < n && y < n;
   const int pix = inb ? y * n + x : 0;
-  const int l0 = inb ? g.leaf_off[pix] : 0, l1 = inb ? g.leaf_off[pix + 1] : 0;
+  const int tile = blockIdx.y * gridDim.x + blockIdx.x;
+  const int nl = g.tile_nl[tile];
   const int nsurf = w.nsurf;
   const double rinv = w.rinv, hw = w.halfwidth, voff = w.voff;
-  const double2* gw = geom + (long long)wi * 4 * g.nleaf;
+  // this thread's first slot; rank i of surface s is at gw[s*nslot + i*256]
+  const double2* gw = geom + (long long)wi * 4 * g.nslot + g.tile_goff[tile] + tid;
   const long long ftile = (long long)gridDim.y * gridDim.x;
-  unsigned char* fl = flags + (long long)wi * g.nv * ftile + (long long)blockIdx.y * gridDim.x + blockIdx.x;
-  const int kf = cix * CH + tid;                          // flag writer: thread c -> channel c
-  const double cmin = g.ch_vmin[cix], cmax = g.ch_vmax[cix];
-  const double* vk = g.vpad + cix * CH;
-  double acc[CH];
-#pragma unroll
-  for (int c = 0; c < CH; ++c) acc[c] = 0.0;
-  bool hit = false;
+  unsigned char* fl = flags + (long long)wi * g.nv * ftile + tile;
+
   __syncthreads();                                        // s_prof ready
-  for (int lf = l0; lf < l1; ++lf) {
-    double2 q[4];                                         // 4 independent 16-B loads per sample
+  {
+    const int kf = cix * CH + tid;                        // flag writer: thread c -> channel c
+    const double cmin = g.ch_vmin[cix], cmax = g.ch_vmax[cix];
+    const double* vk = g.vpad + cix * CH;
+    double acc[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) acc[c] = 0.0;
+    bool hit = false;
+    double2 q[4], qn[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s)
-      q[s] = s < nsurf ? gw[(long long)s * g.nleaf + lf] : make_double2(VL_MASKED, 0.0);
+      qn[s] = (s < nsurf && nl > 0) ? gw[(long long)s * g.nslot] : make_double2(VL_MASKED, 0.0);
+    for (int i = 0; i < nl; ++i) {
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const double vl = q[s].x, wt = q[s].y;
-      const double o = vl + voff;
-      if (cmin - o > hw || o - cmax > hw) continue;       // no channel of this block is lit
-      hit = true;
+      for (int s = 0; s < 4; ++s) q[s] = qn[s];
+      if (i + 1 < nl) {                                   // next rank's loads fly during this one
 #pragma unroll
-      for (int c = 0; c < CH; ++c) {
-        const int idx = prof_index(vk[c], vl, o, rinv, g, w);
-        acc[c] = fma(s_prof[idx], wt, acc[c]);
+        for (int s = 0; s < 4; ++s)
+          qn[s] = s < nsurf ? gw[(long long)s * g.nslot + (i + 1) * 256] : make_double2(VL_MASKED, 0.0);
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const double vl = q[s].x, wt = q[s].y;
+        const double o = vl + voff;
+        if (cmin - o > hw || o - cmax > hw) continue;     // no channel of this block is lit
+        hit = true;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+          const int idx = prof_index(vk[c], vl, o, rinv, g, w);
+          acc[c] = fma(s_prof[idx], wt, acc[c]);
+        }
       }
     }
-  }
-  if (!__syncthreads_or(hit)) {                           // empty sky in this channel block
-    if (tid < CH && kf < g.nv) fl[(long long)kf * ftile] = 0;
-    return;
-  }
-  unsigned m = 0;
-#pragma unroll
-  for (int c = 0; c < CH; ++c) m |= (unsigned)(acc[c] != 0.0) << c;
-  m = wave_or(m);
-  if ((tid & 63) == 0) s_mask[tid >> 6] = m;
-  __syncthreads();
-  m = s_mask[0] | s_mask[1] | s_mask[2] | s_mask[3];
-  if (tid < CH && kf < g.nv) {
-    fl[(long long)kf * ftile] = (m >> tid) & 1u;
-    if ((m >> tid) & 1u) {                                // mark the conv windows this tile feeds
-      const int px0 = blockIdx.x * PT_X, py0 = blockIdx.y * PT_Y;
-      const int wbx0 = max(0, (px0 - (CONV_TX - 1) - g.ngauss + wsx - 1) / wsx);
-      const int wbx1 = min(wnx - 1, (px0 + PT_X - 1 + g.ngauss) / wsx);
-      const int wby0 = max(0, (py0 - wsy - g.ngauss + wsy - 1) / wsy);
-      const int wby1 = min(wny - 1, (py0 + PT_Y - 1 + g.ngauss) / wsy);
-      unsigned char* wf = winflag + ((long long)wi * g.nv + kf) * wnx * wny;
-      for (int by = wby0; by <= wby1; ++by)
-        for (int bx = wbx0; bx <= wbx1; ++bx) wf[by * wnx + bx] = 1;
+    if (!__syncthreads_or(hit)) {                         // empty sky in this channel block
+      if (tid < CH && kf < g.nv) fl[(long long)kf * ftile] = 0;
+      return;
     }
-  }
-  double* out = iunif + (long long)wi * g.nv * npx + pix;
+    unsigned m = 0;
 #pragma unroll
-  for (int c = 0; c < CH; ++c) {
-    const int k = cix * CH + c;
-    if (((m >> c) & 1u) && inb && k < g.nv) out[(long long)k * npx] = acc[c];
+    for (int c = 0; c < CH; ++c) m |= (unsigned)(acc[c] != 0.0) << c;
+    m = wave_or(m);
+    if ((tid & 63) == 0) s_mask[tid >> 6] = m;
+    __syncthreads();
+    m = s_mask[0] | s_mask[1] | s_mask[2] | s_mask[3];
+    if (tid < CH && kf < g.nv) {
+      fl[(long long)kf * ftile] = (m >> tid) & 1u;
+      if ((m >> tid) & 1u) {                              // mark the conv windows this tile feeds
+        const int px0 = blockIdx.x * PT_X, py0 = blockIdx.y * PT_Y;
+        const int wbx0 = max(0, (px0 - (CONV_TX - 1) - g.ngauss + wsx - 1) / wsx);
+        const int wbx1 = min(wnx - 1, (px0 + PT_X - 1 + g.ngauss) / wsx);
+        const int wby0 = max(0, (py0 - wsy - g.ngauss + wsy - 1) / wsy);
+        const int wby1 = min(wny - 1, (py0 + PT_Y - 1 + g.ngauss) / wsy);
+        unsigned char* wf = winflag + ((long long)wi * g.nv + kf) * wnx * wny;
+        for (int by = wby0; by <= wby1; ++by)
+          for (int bx = wbx0; bx <= wbx1; ++bx) wf[by * wnx + bx] = 1;
+      }
+    }
+    double* out = iunif + (long long)wi * g.nv * npx + pix;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const int k = cix * CH + c;
+      if (((m >> c) & 1u) && inb && k < g.nv) out[(long long)k * npx] = acc[c];
+    }
   }
 }
 
@@ -1359,7 +1380,7 @@ int run_model(slamhip_ctx* c, const double* d_params, int nw, hipStream_t st, bo
   }
   {
     Timed t_(c, KID_SURFACE, st);
-    dim3 g1((unsigned)((k.nleaf + 255) / 256), 1, nw);
+    dim3 g1((unsigned)((k.nslot + 255) / 256), 1, nw);
     hipLaunchKernelGGL(k_surface, g1, dim3(256), 0, st, k, c->d_wk, c->d_geom);
   }
   {
@@ -1466,16 +1487,35 @@ int slamhip_create(const slamhip_desc* d, slamhip_ctx** out) {
   const size_t ncube = (size_t)k.nv * k.ny * k.nx;
 
   // --- sample list ---------------------------------------------------------
+  // Samples that survive the layer merge, grouped per 32x8 pixel tile as
+  // [sample rank][pixel in tile] and padded to the tile's largest count, so
+  // that the lanes of k_profile (= pixels) read consecutive slots for a rank.
+  const int ftx = (n + PT_X - 1) / PT_X, fty = (n + PT_Y - 1) / PT_Y;
   std::vector<unsigned> leaves;
-  std::vector<int> off((size_t)n * n + 1);
-  leaves.reserve((size_t)n * n * 3);
-  for (int j = 0; j < n; ++j)
-    for (int i = 0; i < n; ++i) {
-      off[(size_t)j * n + i] = (int)leaves.size();
-      collect_leaves(*d, 0, j + k.ineed0, i + k.ineed0, leaves);
-    }
-  off[(size_t)n * n] = (int)leaves.size();
-  k.nleaf = (long long)leaves.size();
+  std::vector<int> tile_goff((size_t)ftx * fty), tile_nl((size_t)ftx * fty);
+  long long nleaf = 0;
+  {
+    std::vector<unsigned> tmp;
+    std::vector<std::vector<unsigned>> per(PT_X * PT_Y);
+    for (int ty = 0; ty < fty; ++ty)
+      for (int tx = 0; tx < ftx; ++tx) {
+        int nl = 0;
+        for (int p = 0; p < PT_X * PT_Y; ++p) {
+          per[p].clear();
+          const int i = tx * PT_X + (p % PT_X), j = ty * PT_Y + p / PT_X;
+          if (i < n && j < n) collect_leaves(*d, 0, j + k.ineed0, i + k.ineed0, per[p]);
+          nl = std::max(nl, (int)per[p].size());
+          nleaf += (long long)per[p].size();
+        }
+        tile_goff[(size_t)ty * ftx + tx] = (int)leaves.size();
+        tile_nl[(size_t)ty * ftx + tx] = nl;
+        for (int r = 0; r < nl; ++r)
+          for (int p = 0; p < PT_X * PT_Y; ++p)
+            leaves.push_back(r < (int)per[p].size() ? per[p][r] : LEAF_PAD);
+      }
+  }
+  k.nleaf = nleaf;
+  k.nslot = (long long)leaves.size();
 
   // --- data statistics -------------------------------------------------------
   {
@@ -1570,10 +1610,11 @@ int slamhip_create(const slamhip_desc* d, slamhip_ctx** out) {
   if ((rc = dev_upload(c, &k.gx_pad, gx.data(), gx.size()))) return rc;
   if ((rc = dev_upload(c, &k.gy_pad, gy.data(), gy.size()))) return rc;
   if ((rc = dev_upload(c, &k.leaf, leaves.data(), leaves.size()))) return rc;
-  if ((rc = dev_upload(c, &k.leaf_off, off.data(), off.size()))) return rc;
+  if ((rc = dev_upload(c, &k.tile_goff, tile_goff.data(), tile_goff.size()))) return rc;
+  if ((rc = dev_upload(c, &k.tile_nl, tile_nl.data(), tile_nl.size()))) return rc;
 
   // --- per-group scratch -----------------------------------------------------
-  const size_t per_walker = sizeof(double) * (8 * (size_t)k.nleaf + 2 * (size_t)k.nv * n * n);
+  const size_t per_walker = sizeof(double) * (8 * (size_t)k.nslot + 2 * (size_t)k.nv * n * n);
   size_t freeb = 0, totalb = 0;
   HIP_TRY(c, hipMemGetInfo(&freeb, &totalb));
   size_t budget = d->max_scratch_bytes > 0 ? (size_t)d->max_scratch_bytes : ((size_t)24 << 30);
@@ -1587,7 +1628,7 @@ int slamhip_create(const slamhip_desc* d, slamhip_ctx** out) {
   const size_t W = c->wgroup;
   if ((rc = dev_alloc(c, &c->d_wk, W))) return rc;
   if ((rc = dev_alloc(c, &c->d_params, W * NP))) return rc;
-  if ((rc = dev_alloc(c, &c->d_geom, W * 4 * k.nleaf))) return rc;
+  if ((rc = dev_alloc(c, &c->d_geom, W * 4 * k.nslot))) return rc;
   if ((rc = dev_alloc(c, &c->d_iunif, W * k.nv * n * n))) return rc;
   if ((rc = dev_alloc(c, &c->d_iconv, W * k.nv * n * n))) return rc;
   if ((rc = dev_alloc(c, &c->d_partial, W * max_blocks * 3))) return rc;
