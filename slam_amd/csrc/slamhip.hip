@@ -36,7 +36,7 @@ constexpr int PROF_LEN = SLAMHIP_PROF_LEN;   // 45
 constexpr int PROF_N = PROF_LEN - 1;         // 44 (:427)
 constexpr double VL_MASKED = 1.0e300;        // stands in for a NaN vlos
 constexpr double IDX_GUARD = 1.0e-9;         // |iv - integer| below this -> exact path
-constexpr int CH = 32;                       // channels accumulated in registers
+constexpr int CH = 16;                       // channels accumulated in registers
 constexpr int CONV_TX = 64;                  // conv tile width (= one wave)
 constexpr int CONV_R = 8;                    // outputs per thread along the tap axis
 constexpr int RED_THREADS = 256;
