@@ -725,7 +725,8 @@ k_conv_chi2(FitK g, const double* __restrict__ iunif,
   const int rows = TY + kpad - 1, cols = TX + kpad - 1;
   const int P = cols | 1;
   const int vrows = TY + K - 1, vcols = TX + K - 1;
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave index, kept scalar
   double* wxl = lds + rows * P;                             // flipped taps, zero padded
   double* wyl = wxl + kpad;
   for (int e = tid; e < kpad; e += CV_NT) { wxl[e] = g.gx_pad[e]; wyl[e] = g.gy_pad[e]; }
@@ -877,16 +878,16 @@ k_conv_chi2(FitK g, const double* __restrict__ iunif,
     __syncthreads();
 
     // -- 3. row pass over the rows with emission: tmp[row][x] = sum_u gxf[u] tile[row][x+u]
-    const int nitem = nlr * (TX / R);
+    //       wave <-> block of R output columns, lanes <-> rows (odd pitch: conflict-free)
     double res[MAXR][R];
 #pragma unroll
     for (int q = 0; q < MAXR; ++q) {
-      const int item = q * CV_NT + tid;
+      const int ridx = q * 64 + lane;
 #pragma unroll
       for (int r = 0; r < R; ++r) res[q][r] = 0.0;
-      if (item < nitem) {
-        const int xb = item / nlr, rr = s_rowlist[item - xb * nlr];
-        const double* row = lds + rr * P + xb * R;
+      if (q * 64 < nlr && ridx < nlr) {
+        const int rr = s_rowlist[ridx];
+        const double* row = lds + rr * P + wv * R;
         double win[R];
 #pragma unroll
         for (int r = 0; r < R - 1; ++r) win[r] = row[r];
@@ -904,21 +905,24 @@ k_conv_chi2(FitK g, const double* __restrict__ iunif,
     }
     __syncthreads();
     // rows without emission convolve to zero; the others come from registers
-    for (int q = tid; q < rows * (TX / R); q += CV_NT) {
-      const int rr = q / (TX / R), xb = q - rr * (TX / R);
-      const unsigned long long mw = rr < 64 ? m0 : rr < 128 ? m1 : rr < 192 ? m2 : m3;
-      if (!((mw >> (rr & 63)) & 1ull)) {
 #pragma unroll
-        for (int r = 0; r < R; ++r) lds[rr * P2 + xb * R + r] = 0.0;
+    for (int q = 0; q < MAXR; ++q) {
+      const int rr = q * 64 + lane;
+      if (rr < rows) {
+        const unsigned long long mw = q == 0 ? m0 : q == 1 ? m1 : q == 2 ? m2 : m3;
+        if (!((mw >> lane) & 1ull)) {
+#pragma unroll
+          for (int r = 0; r < R; ++r) lds[rr * P2 + wv * R + r] = 0.0;
+        }
       }
     }
 #pragma unroll
     for (int q = 0; q < MAXR; ++q) {
-      const int item = q * CV_NT + tid;
-      if (item < nitem) {
-        const int xb = item / nlr, rr = s_rowlist[item - xb * nlr];
+      const int ridx = q * 64 + lane;
+      if (ridx < nlr) {
+        const int rr = s_rowlist[ridx];
 #pragma unroll
-        for (int r = 0; r < R; ++r) lds[rr * P2 + xb * R + r] = res[q][r];
+        for (int r = 0; r < R; ++r) lds[rr * P2 + wv * R + r] = res[q][r];
       }
     }
     __syncthreads();
