@@ -647,12 +647,16 @@ k_conv_sep(FitK g, const double* __restrict__ in, double* __restrict__ out,
     }
 }
 
+constexpr int WIN_IDS = 32;
 // One live conv window, everything k_conv_chi2 needs to start loading at once.
 struct __attribute__((aligned(16))) WinDesc {
   int e;                         // window id: (walker*nv + channel)*wnx*wny + by*wnx + bx
   int ixa, ixb, jya, jyb;        // observed pixel ranges whose cells it owns
-  int pad[3];
-  unsigned long long occ[FLAG_MAX / 64];   // occupied 32x8 input tiles under the window
+  int nocc;                      // occupied 32x8 input tiles under the window
+  int pad[2];
+  unsigned long long rowmask[4]; // window rows that hold emission
+  unsigned short ids[WIN_IDS];   // the first WIN_IDS occupied tiles (index fy*fnx+fx)
+  unsigned long long occ[FLAG_MAX / 64];   // all of them, as a bitmap
 };
 
 // k_compact: list of conv windows that contain emission (order irrelevant:
@@ -681,15 +685,33 @@ k_compact(FitK g, const unsigned char* __restrict__ winflag, int total,
   d.ixb = tile_ix[((long long)wi * wnx + tbx) * 2 + 1];
   d.jya = tile_jy[((long long)wi * wny + tby) * 2];
   d.jyb = tile_jy[((long long)wi * wny + tby) * 2 + 1];
-  d.pad[0] = d.pad[1] = d.pad[2] = 0;
+  d.pad[0] = d.pad[1] = 0;
 #pragma unroll
   for (int q = 0; q < FLAG_MAX / 64; ++q) d.occ[q] = 0ull;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) d.rowmask[q] = 0ull;
+#pragma unroll
+  for (int q = 0; q < WIN_IDS; ++q) d.ids[q] = 0;
   const unsigned char* fl = flags + (long long)z * ftx * fty;
-  for (int fy = 0; fy < fny; ++fy)
+  int nocc = 0;
+  for (int fy = 0; fy < fny; ++fy) {
+    bool any = false;
     for (int fx = 0; fx < fnx; ++fx) {
       const int q = fy * fnx + fx;
-      if (fl[(long long)(fty0 + fy) * ftx + ftx0 + fx]) d.occ[q >> 6] |= 1ull << (q & 63);
+      if (fl[(long long)(fty0 + fy) * ftx + ftx0 + fx]) {
+        d.occ[q >> 6] |= 1ull << (q & 63);
+        if (nocc < WIN_IDS) d.ids[nocc] = (unsigned short)q;
+        ++nocc;
+        any = true;
+      }
     }
+    if (any) {
+      const int r0 = max((fty0 + fy) * PT_Y - wy0, 0);
+      const int r1 = min((fty0 + fy + 1) * PT_Y - wy0, vrows);   // exclusive
+      for (int r = r0; r < r1; ++r) d.rowmask[r >> 6] |= 1ull << (r & 63);
+    }
+  }
+  d.nocc = nocc;
   list[atomicAdd(count, 1)] = d;
 }
 
@@ -719,7 +741,6 @@ k_conv_chi2(FitK g, const double* __restrict__ iunif,
   constexpr int NRQ = (TY - 1 + CV_NW - 1) / CV_NW;         // regrid rows per wave
   constexpr int NSB = 2;                                    // staged tiles per wave held in registers
   __shared__ unsigned char s_rowlist[256];
-  __shared__ unsigned long long s_rowmask[2][4];            // tile rows with emission (<= 256)
   __shared__ double sg[CV_NW], sf[CV_NW];
   const int K = g.kbeam, ng = g.ngauss, n = g.nneed;
   const int rows = TY + kpad - 1, cols = TX + kpad - 1;
@@ -730,11 +751,10 @@ k_conv_chi2(FitK g, const double* __restrict__ iunif,
   double* wxl = lds + rows * P;                             // flipped taps, zero padded
   double* wyl = wxl + kpad;
   for (int e = tid; e < kpad; e += CV_NT) { wxl[e] = g.gx_pad[e]; wyl[e] = g.gy_pad[e]; }
-  if (tid < 8) s_rowmask[tid >> 2][tid & 3] = 0ull;
   __syncthreads();
   const int nlive = *count;
   constexpr int DW = sizeof(WinDesc) / 4;                   // descriptor dwords
-  __shared__ unsigned s_desc[2][DW];
+  __shared__ __attribute__((aligned(16))) unsigned s_desc[2][DW];
   if (tid < DW && (int)blockIdx.x < nlive)
     s_desc[0][tid] = reinterpret_cast<const unsigned*>(&list[blockIdx.x])[tid];
   __syncthreads();
@@ -745,8 +765,8 @@ k_conv_chi2(FitK g, const double* __restrict__ iunif,
     unsigned nextw = 0;
     if (tid < DW && it + (int)gridDim.x < nlive)
       nextw = reinterpret_cast<const unsigned*>(&list[it + gridDim.x])[tid];
-    const unsigned long long* occ = reinterpret_cast<const unsigned long long*>(&s_desc[par][8]);
-    const int e = (int)s_desc[par][0];
+    const WinDesc* cur = reinterpret_cast<const WinDesc*>(&s_desc[par][0]);   // in LDS
+    const int e = cur->e;
     const int z = e / (wnx * wny), tl = e - z * (wnx * wny);
     const int tby = tl / wnx, tbx = tl - tby * wnx;
     const int wi = z / g.nv, k = z - wi * g.nv;
@@ -755,51 +775,41 @@ k_conv_chi2(FitK g, const double* __restrict__ iunif,
     const int wx0 = x0 - ng, wy0 = y0 - ng;                 // window origin (image coords)
     const int ftx0 = max(wx0, 0) / PT_X, fty0 = max(wy0, 0) / PT_Y;
     const int fnx = min(wx0 + vcols - 1, n - 1) / PT_X - ftx0 + 1;
-    const int fny = min(wy0 + vrows - 1, n - 1) / PT_Y - fty0 + 1;
+    const int nocc = cur->nocc;
 
     // -- 0. issue every global load of this window now: the occupied input
     //       tiles (NSB per wave in registers) and what the regrid needs
     double sv[NSB][4];
     int srr[NSB], scc[NSB];
-    {
-      int seen = 0, slot = 0;
 #pragma unroll
-      for (int u = 0; u < NSB; ++u) { srr[u] = -1; scc[u] = 0; sv[u][0] = sv[u][1] = sv[u][2] = sv[u][3] = 0.0; }
-      for (int qw = 0; qw < FLAG_MAX / 64 && slot < NSB; ++qw) {
-        unsigned long long m = occ[qw];
-        while (m && slot < NSB) {
-          const int q = qw * 64 + __builtin_ctzll(m);
-          m &= m - 1;
-          if ((seen++ & (CV_NW - 1)) != wv) continue;
-          const int fyy = q / fnx, fxx = q - fyy * fnx;
-          const int gy = (fty0 + fyy) * PT_Y + (lane >> 3);
-          const int gx0 = (ftx0 + fxx) * PT_X + (lane & 7) * 4;
-          const int rr = gy - wy0;
-          const bool rowok = gy < n && rr >= 0 && rr < vrows;
+    for (int u = 0; u < NSB; ++u) {
+      const int bq = wv + CV_NW * u;
+      srr[u] = -1;
+      scc[u] = 0;
+      sv[u][0] = sv[u][1] = sv[u][2] = sv[u][3] = 0.0;
+      if (bq < nocc && bq < WIN_IDS) {
+        const int q = cur->ids[bq];
+        const int fyy = q / fnx, fxx = q - fyy * fnx;
+        const int gy = (fty0 + fyy) * PT_Y + (lane >> 3);
+        const int gx0 = (ftx0 + fxx) * PT_X + (lane & 7) * 4;
+        const int rr = gy - wy0;
+        const bool rowok = gy < n && rr >= 0 && rr < vrows;
+        srr[u] = rowok ? rr : -1;
+        scc[u] = gx0 - wx0;
 #pragma unroll
-          for (int u = 0; u < NSB; ++u)
-            if (u == slot) {
-              srr[u] = rowok ? rr : -1;
-              scc[u] = gx0 - wx0;
-#pragma unroll
-              for (int j = 0; j < 4; ++j) {
-                const int gx = gx0 + j, cc = gx - wx0;
-                sv[u][j] = (rowok && gx < n && cc >= 0 && cc < vcols) ? src[(long long)gy * n + gx] : 0.0;
-              }
-            }
-          ++slot;
+        for (int j = 0; j < 4; ++j) {
+          const int gx = gx0 + j, cc = gx - wx0;
+          sv[u][j] = (rowok && gx < n && cc >= 0 && cc < vcols) ? src[(long long)gy * n + gx] : 0.0;
         }
       }
     }
-    const int* cy = celly + (long long)wi * g.ny;
-    const double* fy = fracy + (long long)wi * g.ny;
     const double* dat = g.data + (long long)k * g.ny * g.nx;
-    const int ixa = (int)s_desc[par][1], ixb = (int)s_desc[par][2], jya = (int)s_desc[par][3],
-              jyb = (int)s_desc[par][4];
+    const int ixa = cur->ixa, ixb = cur->ixb, jya = cur->jya, jyb = cur->jyb;
     const int ix = ixa + lane;
     int i1 = -1;
     double t1 = 0.0;
-    double dv[NRQ];
+    double dv[NRQ], t0q[NRQ];
+    int i0q[NRQ];
     if (ix < ixb) {
       i1 = cellx[(long long)wi * g.nx + ix] - x0;
       t1 = fracx[(long long)wi * g.nx + ix];
@@ -807,30 +817,16 @@ k_conv_chi2(FitK g, const double* __restrict__ iunif,
 #pragma unroll
     for (int q = 0; q < NRQ; ++q) {
       const int jy = jya + wv + CV_NW * q;
-      dv[q] = (ix < ixb && jy < jyb) ? dat[(long long)jy * g.nx + ix] : 0.0;
+      const bool rowin = jy < jyb;
+      i0q[q] = rowin ? celly[(long long)wi * g.ny + jy] - y0 : -1;   // wave-uniform
+      t0q[q] = rowin ? fracy[(long long)wi * g.ny + jy] : 0.0;
+      dv[q] = (ix < ixb && rowin) ? dat[(long long)jy * g.nx + ix] : 0.0;
     }
     const bool xown = i1 >= 0 && i1 < TX - 1;               // else owned by another window
 
-    // -- 1. zero the LDS tile; rows that hold emission
-    for (int q = tid; q < rows * P; q += CV_NT) lds[q] = 0.0;
-    if (tid < fny) {
-      unsigned long long any = 0ull;
-      for (int fxx = 0; fxx < fnx; ++fxx) {
-        const int q = tid * fnx + fxx;
-        any |= (occ[q >> 6] >> (q & 63)) & 1ull;
-      }
-      if (any) {
-        const int r0 = max((fty0 + tid) * PT_Y - wy0, 0);
-        const int r1 = min((fty0 + tid + 1) * PT_Y - wy0, vrows);   // exclusive
-        for (int r = r0; r < r1; ++r) atomicOr(&s_rowmask[par][r >> 6], 1ull << (r & 63));
-      }
-    }
-    __syncthreads();
-
-    // -- 2. list of rows with emission; staged tiles into LDS
-    if (tid < 4) s_rowmask[par ^ 1][tid] = 0ull;
-    const unsigned long long m0 = s_rowmask[par][0], m1 = s_rowmask[par][1],
-                             m2 = s_rowmask[par][2], m3 = s_rowmask[par][3];
+    // -- 1. rows that hold emission; zero them in the LDS tile
+    const unsigned long long m0 = cur->rowmask[0], m1 = cur->rowmask[1],
+                             m2 = cur->rowmask[2], m3 = cur->rowmask[3];
     const int nlr = __popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3);
     if (tid < rows) {
       const unsigned long long mw = tid < 64 ? m0 : tid < 128 ? m1 : tid < 192 ? m2 : m3;
@@ -842,6 +838,22 @@ k_conv_chi2(FitK g, const double* __restrict__ iunif,
         s_rowlist[pos] = (unsigned char)tid;
       }
     }
+    {
+      // wave <-> rows, lanes <-> columns; only rows the row pass will read
+      const double2 zz = make_double2(0.0, 0.0);
+      for (int rr = wv; rr < rows; rr += CV_NW) {
+        const unsigned long long mw = rr < 64 ? m0 : rr < 128 ? m1 : rr < 192 ? m2 : m3;
+        if (!((mw >> (rr & 63)) & 1ull)) continue;          // wave-uniform
+        double* rowp = lds + rr * P;
+        for (int c2 = lane * 2; c2 < P; c2 += 128) {
+          if (c2 + 1 < P) { rowp[c2] = 0.0; rowp[c2 + 1] = 0.0; } else rowp[c2] = 0.0;
+        }
+      }
+      (void)zz;
+    }
+    __syncthreads();
+
+    // -- 2. staged tiles into LDS
 #pragma unroll
     for (int u = 0; u < NSB; ++u)
       if (srr[u] >= 0) {
@@ -851,16 +863,17 @@ k_conv_chi2(FitK g, const double* __restrict__ iunif,
           if (cc >= 0 && cc < vcols) lds[srr[u] * P + cc] = sv[u][j];
         }
       }
-    {
-      // occupied tiles beyond NSB per wave (crowded windows): load and store directly
-      int seen = 0, mine = 0;
+    if (nocc > NSB * CV_NW) {
+      // crowded window: the remaining occupied tiles, loaded and stored directly
+      const unsigned long long* occ = cur->occ;
+      int seen = 0;
       for (int qw = 0; qw < FLAG_MAX / 64; ++qw) {
         unsigned long long m = occ[qw];
         while (m) {
           const int q = qw * 64 + __builtin_ctzll(m);
           m &= m - 1;
-          if ((seen++ & (CV_NW - 1)) != wv) continue;
-          if (mine++ < NSB) continue;
+          const int b = seen++;
+          if (b < NSB * CV_NW || (b & (CV_NW - 1)) != wv) continue;
           const int fyy = q / fnx, fxx = q - fyy * fnx;
           const int gy = (fty0 + fyy) * PT_Y + (lane >> 3);
           const int gx0 = (ftx0 + fxx) * PT_X + (lane & 7) * 4;
@@ -968,9 +981,9 @@ k_conv_chi2(FitK g, const double* __restrict__ iunif,
     for (int q = 0; q < NRQ; ++q) {
       const int jy = jya + wv + CV_NW * q;
       if (jy < jyb) {
-        const int i0 = cy[jy] - y0;                         // wave-uniform
+        const int i0 = i0q[q];                              // wave-uniform
         if (xown && i0 >= 0 && i0 < TY - 1) {
-          const double t0 = fy[jy];
+          const double t0 = t0q[q];
           const double* c = lds + i0 * PC + i1;
           const double v00 = c[0], v01 = c[1], v10 = c[PC], v11 = c[PC + 1];
           const double val = v00 * (1 - t0) * (1 - t1) + v01 * (1 - t0) * t1 +
@@ -986,9 +999,9 @@ k_conv_chi2(FitK g, const double* __restrict__ iunif,
       if (i1b < 0 || i1b >= TX - 1) continue;
       const double t1b = fracx[(long long)wi * g.nx + ix2];
       for (int jy = jya + wv + (ix2 == ix ? CV_NW * NRQ : 0); jy < jyb; jy += CV_NW) {
-        const int i0 = cy[jy] - y0;
+        const int i0 = celly[(long long)wi * g.ny + jy] - y0;
         if (i0 < 0 || i0 >= TY - 1) continue;
-        const double t0 = fy[jy];
+        const double t0 = fracy[(long long)wi * g.ny + jy];
         const double* c = lds + i0 * PC + i1b;
         const double val = c[0] * (1 - t0) * (1 - t1b) + c[1] * (1 - t0) * t1b +
                            c[PC] * t0 * (1 - t1b) + c[PC + 1] * t0 * t1b;
