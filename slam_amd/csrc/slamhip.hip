@@ -234,33 +234,31 @@ __global__ void k_prep(FitK g, const double* __restrict__ params, int nw,
 // ---------------------------------------------------------------------------
 struct Surf { double x, r, vlos; };
 
-__device__ inline Surf surface_eval(const FitK& g, const WalkerK& w, int s,
-                                    double X, double Y) {
-  const double nan = __builtin_nan("");
+// Deprojected minor-axis coordinate on surface s (update_xdisk, :382-410).
+__device__ inline double surface_x(const WalkerK& w, int s, double X, double Y) {
   const int kind = w.kind[s];
   const double hh = w.h2[s];
-  double x;
-  if (kind == 1) {
-    x = X / w.cosi;                                        // :389
-  } else {
-    const double Xc = X * w.cosi;                          // :392
-    const double b = (1.0 + hh) * Xc;                      // :394
-    const double c = w.qk[s] * (Xc * Xc) - hh * (Y * Y);   // :395-396
-    if (kind == 2) {
-      x = Xc + c / b / 2.0;                                // :398
-    } else {
-      const double a = w.qa[s];
-      const double D = b * b - a * c;                      // :403
-      if (D >= 0) {
-        const double rt = sqrt(D);
-        const double z = (kind == 3 ? (b + rt) : (b - rt)) / a;  // :405-406
-        x = Xc + z;
-      } else {
-        x = nan;
-      }
-    }
-  }
-  const double r = hypot(x, Y);                            // :433
+  if (kind == 1) return X / w.cosi;                        // :389
+  const double Xc = X * w.cosi;                            // :392
+  const double b = (1.0 + hh) * Xc;                        // :394
+  const double c = w.qk[s] * (Xc * Xc) - hh * (Y * Y);     // :395-396
+  if (kind == 2) return Xc + c / b / 2.0;                  // :398
+  const double a = w.qa[s];
+  const double D = b * b - a * c;                          // :403
+  if (!(D >= 0)) return __builtin_nan("");
+  const double rt = sqrt(D);
+  return Xc + (kind == 3 ? (b + rt) : (b - rt)) / a;       // :405-408
+}
+
+// True where getvlos (:443-447) leaves NaN whatever the velocity is.
+__device__ inline bool surface_masked(const FitK& g, const WalkerK& w, double r) {
+  const bool outer = r > w.Rc;                             // :434
+  return !(r == r) || r < w.Rin || (!g.envelope && outer) || (!g.disk && !outer);
+}
+
+// Line-of-sight velocity for Mstar = 1 at (x, Y), radius r (getvlos, :433-447).
+__device__ inline double surface_vlos(const FitK& g, const WalkerK& w, int s,
+                                      double x, double Y, double r) {
   const bool outer = r > w.Rc;                             // :434
   const double rmh = 1.0 / sqrt(r);                        // r**(-1/2)
   double vp = rmh * w.hfac[s];                             // :435
@@ -271,12 +269,16 @@ __device__ inline Surf surface_eval(const FitK& g, const WalkerK& w, int s,
   }
   const double erot = Y * g.signmajor / r;                 // :440
   const double erad = x * g.signminor / r;                 // :441
-  double vlos = (vp * erot + vr * erad) * w.sini * g.vunit;  // :442
-  if (r < w.Rin) vlos = nan;                               // :443
-  if (!g.envelope && outer) vlos = nan;                    // :444-445
-  if (!g.disk && !outer) vlos = nan;                       // :446-447
+  return (vp * erot + vr * erad) * w.sini * g.vunit;       // :442
+}
+
+__device__ inline Surf surface_eval(const FitK& g, const WalkerK& w, int s,
+                                    double X, double Y) {
   Surf o;
-  o.x = x; o.r = r; o.vlos = vlos;
+  o.x = surface_x(w, s, X, Y);
+  // hypot without the overflow rescaling (|x|,|Y| are grid coordinates): <= 1 ulp
+  o.r = sqrt(fma(o.x, o.x, Y * Y));                        // :433
+  o.vlos = surface_masked(g, w, o.r) ? __builtin_nan("") : surface_vlos(g, w, s, o.x, Y, o.r);
   return o;
 }
 
@@ -305,10 +307,15 @@ k_surface(FitK g, const WalkerK* __restrict__ wk, double2* __restrict__ geom) {
   const double Y = X0 * w.sp + Y0 * w.cp;                  // utils.py:356
   const double lw = 1.0 / (double)(1 << (2 * l));          // avefour nesting :469-471
   for (int s = 0; s < w.nsurf; ++s) {
-    const Surf f = surface_eval(g, w, s, X, Y);
-    double vl = f.vlos * w.sqrtM;                          // :460
-    double wt = (f.r < w.Rc ? 1.0 : w.Ienv) * w.inv_ienv1; // :465
-    if (w.pI != 0.0) wt = wt * pow(f.r, -w.pI);            // :466-467
+    const double xs = surface_x(w, s, X, Y);
+    const double r = sqrt(fma(xs, xs, Y * Y));             // :433
+    if (surface_masked(g, w, r)) {                         // NaN vlos: most of the sky, skip the rest
+      geom[((long long)wi * 4 + s) * g.nslot + leaf] = make_double2(VL_MASKED, 0.0);
+      continue;
+    }
+    double vl = surface_vlos(g, w, s, xs, Y, r) * w.sqrtM; // :460
+    double wt = (r < w.Rc ? 1.0 : w.Ienv) * w.inv_ienv1;   // :465
+    if (w.pI != 0.0) wt = wt * exp(-w.pI * log(r));        // r**(-pI), :466-467
     wt = wt * (lw * w.wmul[s]);
     if (!(vl == vl) || !(wt == wt)) {                      // NaN -> contributes 0 (:463,:468)
       vl = VL_MASKED;
