@@ -381,28 +381,37 @@ __device__ inline unsigned wave_or(unsigned v) {
 // pre-zeroed buffer (dense taps).
 __global__ void __launch_bounds__(256)
 k_profile(FitK g, const WalkerK* __restrict__ wk, const double2* __restrict__ geom,
-          double* __restrict__ iunif, unsigned char* __restrict__ flags,
+          double* __restrict__ iunif, unsigned char* __restrict__ flags, int ftx, int fty,
           unsigned char* __restrict__ winflag, int wnx, int wny, int wsx, int wsy) {
   __shared__ double s_prof[PROF_LEN];
   __shared__ unsigned s_mask[4];
+  // XCD-aware block order: blocks b and b+8 share an XCD (and its L2), so the
+  // channel blocks of one pixel tile, which all read the tile's geometry, are
+  // given ids 8 apart: id = ((tile/8 * nchunk + cix) * 8 + tile%8) per walker.
   const int nchunk = g.nvpad / CH;
-  const int wi = blockIdx.z / nchunk, cix = blockIdx.z - wi * nchunk;
+  const int ntile = ftx * fty, tgroups = (ntile + 7) / 8;
+  const int per_walker = tgroups * nchunk * 8;
+  const int wi = blockIdx.x / per_walker;
+  const int lid = blockIdx.x - wi * per_walker;
+  const int cix = (lid >> 3) % nchunk;
+  const int tile = ((lid >> 3) / nchunk) * 8 + (lid & 7);
+  if (tile >= ntile) return;
+  const int tby = tile / ftx, tbx = tile - tby * ftx;
   const WalkerK& w = wk[wi];
   const int tid = threadIdx.x;
   if (tid < PROF_LEN) s_prof[tid] = w.prof[tid];
   const int n = g.nneed;
   const int npx = n * n;
-  const int x = blockIdx.x * PT_X + (tid & (PT_X - 1));
-  const int y = blockIdx.y * PT_Y + tid / PT_X;
+  const int x = tbx * PT_X + (tid & (PT_X - 1));
+  const int y = tby * PT_Y + tid / PT_X;
   const bool inb = x < n && y < n;
   const int pix = inb ? y * n + x : 0;
-  const int tile = blockIdx.y * gridDim.x + blockIdx.x;
   const int nl = g.tile_nl[tile];
   const int nsurf = w.nsurf;
   const double rinv = w.rinv, hw = w.halfwidth, voff = w.voff;
   // this thread's first slot; rank i of surface s is at gw[s*nslot + i*256]
   const double2* gw = geom + (long long)wi * 4 * g.nslot + g.tile_goff[tile] + tid;
-  const long long ftile = (long long)gridDim.y * gridDim.x;
+  const long long ftile = ntile;
   unsigned char* fl = flags + (long long)wi * g.nv * ftile + tile;
 
   __syncthreads();                                        // s_prof ready
@@ -414,6 +423,9 @@ k_profile(FitK g, const WalkerK* __restrict__ wk, const double2* __restrict__ ge
 #pragma unroll
     for (int c = 0; c < CH; ++c) acc[c] = 0.0;
     bool hit = false;
+    double vks[CH];                                       // this block's channel velocities (scalar)
+#pragma unroll
+    for (int c = 0; c < CH; ++c) vks[c] = vk[c];
     double2 q[4], qn[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s)
@@ -426,17 +438,35 @@ k_profile(FitK g, const WalkerK* __restrict__ wk, const double2* __restrict__ ge
         for (int s = 0; s < 4; ++s)
           qn[s] = s < nsurf ? gw[(long long)s * g.nslot + (i + 1) * 256] : make_double2(VL_MASKED, 0.0);
       }
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const double vl = q[s].x, wt = q[s].y;
+#pragma unroll 1
+      for (int s = 0; s < nsurf; ++s) {
+        const double vl = s == 0 ? q[0].x : s == 1 ? q[1].x : s == 2 ? q[2].x : q[3].x;
+        const double wt = s == 0 ? q[0].y : s == 1 ? q[1].y : s == 2 ? q[2].y : q[3].y;
         const double o = vl + voff;
         if (cmin - o > hw || o - cmax > hw) continue;     // no channel of this block is lit
         hit = true;
+        // table index of every channel, fast form (differs from the reference's
+        // iv by < 1e-12); lanes within IDX_GUARD of an integer redo it exactly
+        int idx[CH];
+        bool near = false;
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
-          const int idx = prof_index(vk[c], vl, o, rinv, g, w);
-          acc[c] = fma(s_prof[idx], wt, acc[c]);
+          const double t = fma(vks[c] - o, rinv, 22.5);
+          near |= fabs(t - rint(t)) < IDX_GUARD;
+          idx[c] = (int)t;                                // saturating; NaN -> 0
         }
+        if (near) {
+          // iv = ((v_valid - vlos) - voff) / dv / prof_d + prof_n//2 + 0.5   (:461-462)
+#pragma unroll
+          for (int c = 0; c < CH; ++c) {
+            double v = vks[c] - vl;
+            v = v - voff;
+            idx[c] = (int)(v / g.dv / w.prof_d + 22.0 + 0.5);
+          }
+        }
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+          acc[c] = fma(s_prof[min(max(idx[c], 0), PROF_N)], wt, acc[c]);
       }
     }
     if (!__syncthreads_or(hit)) {                         // empty sky in this channel block
@@ -453,7 +483,7 @@ k_profile(FitK g, const WalkerK* __restrict__ wk, const double2* __restrict__ ge
     if (tid < CH && kf < g.nv) {
       fl[(long long)kf * ftile] = (m >> tid) & 1u;
       if ((m >> tid) & 1u) {                              // mark the conv windows this tile feeds
-        const int px0 = blockIdx.x * PT_X, py0 = blockIdx.y * PT_Y;
+        const int px0 = tbx * PT_X, py0 = tby * PT_Y;
         const int wbx0 = max(0, (px0 - (CONV_TX - 1) - g.ngauss + wsx - 1) / wsx);
         const int wbx1 = min(wnx - 1, (px0 + PT_X - 1 + g.ngauss) / wsx);
         const int wby0 = max(0, (py0 - wsy - g.ngauss + wsy - 1) / wsy);
@@ -1409,9 +1439,10 @@ int run_model(slamhip_ctx* c, const double* d_params, int nw, hipStream_t st, bo
   }
   {
     Timed t_(c, KID_PROFILE, st);
-    dim3 g2(c->ftx, c->fty, nw * (k.nvpad / CH));
+    const int tgroups = (c->ftx * c->fty + 7) / 8;
+    dim3 g2((unsigned)tgroups * 8u * (unsigned)(k.nvpad / CH) * (unsigned)nw, 1, 1);
     hipLaunchKernelGGL(k_profile, g2, dim3(256), 0, st, k, c->d_wk, c->d_geom,
-                       c->d_iunif, c->d_flags, c->d_winflag, (int)c->fz_grid.x, (int)c->fz_grid.y,
+                       c->d_iunif, c->d_flags, c->ftx, c->fty, c->d_winflag, (int)c->fz_grid.x, (int)c->fz_grid.y,
                        c->fz_sx, c->fz_sy);
   }
   HIP_TRY(c, hipGetLastError());
