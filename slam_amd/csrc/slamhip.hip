@@ -1619,9 +1619,9 @@ int slamhip_create(const slamhip_desc* d, slamhip_ctx** out) {
   c->sep_variant = -1;
   if (sep_lds_bytes(64, c->kpad) <= 80 * 1024 && (64 + c->kpad - 1) * (CONV_TX / CONV_R) <= 3 * 256) {
     c->sep_variant = 0; c->sep_lds = sep_lds_bytes(64, c->kpad);
-  } else if (sep_lds_bytes(64, c->kpad) <= 160 * 1024 && (64 + c->kpad - 1) * (CONV_TX / CONV_R) <= 5 * 256) {
+  } else if (sep_lds_bytes(64, c->kpad) + 2 * c->kpad * sizeof(double) <= 156 * 1024 && (64 + c->kpad - 1) * (CONV_TX / CONV_R) <= 5 * 256) {
     c->sep_variant = 1; c->sep_lds = sep_lds_bytes(64, c->kpad);
-  } else if (sep_lds_bytes(32, c->kpad) <= 160 * 1024 && (32 + c->kpad - 1) * (CONV_TX / CONV_R) <= 4 * 256) {
+  } else if (sep_lds_bytes(32, c->kpad) + 2 * c->kpad * sizeof(double) <= 156 * 1024 && (32 + c->kpad - 1) * (CONV_TX / CONV_R) <= 4 * 256) {
     c->sep_variant = 2; c->sep_lds = sep_lds_bytes(32, c->kpad);
   }
   c->c2d_lds = (size_t)(C2_TY + K - 1) * ((C2_TX + K - 1) | 1) * sizeof(double);

@@ -177,3 +177,32 @@ def test_c3_properties():
                        signminor=1)
     np.testing.assert_allclose(got[5], orc.chi2_of(s, P[5]), rtol=1e-9)
     fit.close()
+
+
+@pytest.mark.parametrize('beam_px', [(12, 9), (24, 18)])
+def test_large_beams_pick_other_conv_tiles(beam_px):
+    """K = 39 and K = 77 (BASELINE config 4's beam) select the 64-row/160 KB and
+    the 32-row LDS tile variants of the convolution; both against the oracle."""
+    from slam_amd import synth
+    fit = synth.make_fit('big', N=128, NV=8, beam_px=beam_px)
+    assert fit.engine.separable_beam
+    P = synth.walkers(5)
+    P[:, 0] *= 0.2                     # keep the emission inside the 8 channels
+    got = fit.engine.chi2_stats(P)
+    s = orc.make_setup(fit.x, fit.y, fit.v, fit.data, bmaj=fit.bmaj, bmin=fit.bmin, bpa=fit.bpa,
+                       sigma=fit.sigma, pa=2.0, incl=60.0, rmax=synth.RMAX, signmajor=1,
+                       signminor=1)
+    for i in range(len(P)):
+        st = {}
+        model = orc.cubemodel(s, P[i], stages=st)
+        np.testing.assert_allclose(got['gf'][i], st['gf'], rtol=1e-9)
+        np.testing.assert_allclose(got['ff'][i], st['ff'], rtol=1e-9)
+        np.testing.assert_allclose(got['chi2'][i], orc.chi2(s, model), rtol=1e-9)
+    assert _golden.relmax(fit.engine.iconv(P[0]), st_conv(s, P[0])) < 1e-9
+    fit.close()
+
+
+def st_conv(s, p):
+    st = {}
+    orc.cubemodel(s, p, stages=st)
+    return st['Iconv']
