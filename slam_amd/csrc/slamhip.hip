@@ -1191,22 +1191,28 @@ k_regrid(FitK g, const int* __restrict__ cellx, const double* __restrict__ fracx
 //   chi2  = sum((d - scale*I)^2)/sigma^2/pixperbeam                 (:601-602)
 //         = (sum d^2 - 2 s gf + s^2 ff)/sigma^2/pixperbeam
 // stats[w] = {gf, ff, scale, chi2, non-empty blocks, blocks}
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(256)
 k_finalize(FitK g, const double* __restrict__ partial, int nblk,
            const unsigned char* __restrict__ winflag,
            double* __restrict__ stats, double* __restrict__ chi2_out) {
+  __shared__ double sa[4], sb[4], sl[4];
   const int wi = blockIdx.x;
   const double* p = partial + (long long)wi * nblk * 3;
   const unsigned char* wf = winflag ? winflag + (long long)wi * nblk : nullptr;
   double a = 0.0, b = 0.0, live = 0.0;
-  for (int q = threadIdx.x; q < nblk; q += 64) {
+  for (int q = threadIdx.x; q < nblk; q += 256) {
     if (wf && !wf[q]) continue;          // window never convolved: its slot is stale
     a += p[3 * q]; b += p[3 * q + 1]; live += p[3 * q + 2];
   }
   a = wave_sum(a);
   b = wave_sum(b);
   live = wave_sum(live);
+  if ((threadIdx.x & 63) == 0) { sa[threadIdx.x >> 6] = a; sb[threadIdx.x >> 6] = b; sl[threadIdx.x >> 6] = live; }
+  __syncthreads();
   if (threadIdx.x == 0) {
+    a = (sa[0] + sa[1]) + (sa[2] + sa[3]);
+    b = (sb[0] + sb[1]) + (sb[2] + sb[3]);
+    live = (sl[0] + sl[1]) + (sl[2] + sl[3]);
     double s = a / b;
     if (b == 0.0 || s < 0.0) s = 0.0;
     double c2;
@@ -1480,7 +1486,7 @@ int run_group(slamhip_ctx* c, const double* d_params, int nw, double* d_chi2,
     }
     {
       Timed t_(c, KID_FINALIZE, st);
-      hipLaunchKernelGGL(k_finalize, dim3(nw), dim3(64), 0, st, c->k, c->d_partial,
+      hipLaunchKernelGGL(k_finalize, dim3(nw), dim3(256), 0, st, c->k, c->d_partial,
                          (int)(c->fz_grid.x * c->fz_grid.y * c->fz_grid.z), c->d_winflag,
                          c->d_stats, d_chi2);
     }
@@ -1498,7 +1504,7 @@ int run_group(slamhip_ctx* c, const double* d_params, int nw, double* d_chi2,
   }
   {
     Timed t_(c, KID_FINALIZE, st);
-    hipLaunchKernelGGL(k_finalize, dim3(nw), dim3(64), 0, st, c->k, c->d_partial,
+    hipLaunchKernelGGL(k_finalize, dim3(nw), dim3(256), 0, st, c->k, c->d_partial,
                        c->red_blocks, (const unsigned char*)nullptr, c->d_stats, d_chi2);
   }
   HIP_TRY(c, hipGetLastError());
@@ -1877,7 +1883,7 @@ int slamhip_cubemodel(slamhip_ctx* c, const double* params, int convolving,
   hipLaunchKernelGGL((k_regrid<true>), c->rg_grid, dim3(RED_THREADS), 0, c->stream, k,
                      c->d_cellx, c->d_fracx, c->d_celly, c->d_fracy, c->d_iconv, c->d_partial,
                      d_cube);
-  hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, c->stream, k, c->d_partial, c->red_blocks,
+  hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, c->stream, k, c->d_partial, c->red_blocks,
                      (const unsigned char*)nullptr, c->d_stats, (double*)nullptr);
   hipLaunchKernelGGL(k_scale, dim3(1024), dim3(256), 0, c->stream, d_cube, (long long)ncube, c->d_stats);
   hipError_t e = hipGetLastError();
