@@ -126,7 +126,7 @@ def main():
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': f'SYN-v1 {args.config}: {nx}x{ny}x{nv} cube, '
                                    f'{args.walkers} walkers per GPU per step, beam K={fit.gaussbeam.shape[0]} '
-                                   f'bpa={args.bpa:g} ({"separable" if eng.separable_beam else "direct 2-D"})',
+                                   f'bpa={args.bpa:g} (beam rank {eng.beam_rank})',
                        'walkers_per_gpu': args.walkers, 'walkers_per_launch': eng.walkers_per_group,
                        'npix': eng.npix, 'nneed': n, 'nleaf': eng.nleaf,
                        'chi2_checksum': float(np.sum(chi2))},

@@ -124,8 +124,13 @@ int slamhip_prof(slamhip_ctx* ctx, double cs, double* prof_out,
 int slamhip_info(slamhip_ctx* ctx, int64_t* nleaf, int32_t* walkers_per_group,
                  int32_t* separable_beam);
 
-/* Selects the convolution kernel: 0 = auto (separable when the beam is an
- * outer product to 1e-14, else direct 2-D), 1 = force direct 2-D. */
+/* Number of outer-product terms the fused convolution uses for the beam: 1 for
+ * an axis-aligned Gaussian, the leading singular triplets (tail < 1e-13) for a
+ * rotated one, 0 when the hot path falls back to direct K x K taps. */
+int slamhip_beam_rank(slamhip_ctx* ctx);
+
+/* Selects the convolution kernel: 0 = auto (fused separable / rank-R
+ * kernel when available), 1 = force the dense direct 2-D path. */
 int slamhip_set_conv_mode(slamhip_ctx* ctx, int mode);
 
 /* Measurement aid (no counterpart in the reference): between _begin and _end

@@ -40,6 +40,7 @@ constexpr int CH = 16;                       // channels accumulated in register
 constexpr int CONV_TX = 64;                  // conv tile width (= one wave)
 constexpr int CONV_R = 8;                    // outputs per thread along the tap axis
 constexpr int RED_THREADS = 256;
+constexpr int MAX_RANK = 24;                 // beam outer-product terms the fused kernel accepts
 constexpr unsigned LEAF_PAD = 0xffffffffu;    // slot without a sample
 constexpr int FLAG_MAX = 512;                // occupancy bytes one conv window may span
 
@@ -772,7 +773,7 @@ k_conv_chi2(FitK g, const double* __restrict__ iunif,
             const int* __restrict__ cellx, const double* __restrict__ fracx,
             const int* __restrict__ celly, const double* __restrict__ fracy,
             const WinDesc* __restrict__ list, const int* __restrict__ count, int wnx, int wny,
-            double* __restrict__ partial, int kpad) {
+            double* __restrict__ partial, int kpad, int nrank) {
   extern __shared__ double lds[];
   constexpr int TX = CONV_TX, R = CONV_R, PC = TX + 1, P2 = TX + 1;
   constexpr int NRQ = (TY - 1 + CV_NW - 1) / CV_NW;         // regrid rows per wave
@@ -785,9 +786,14 @@ k_conv_chi2(FitK g, const double* __restrict__ iunif,
   const int vrows = TY + K - 1, vcols = TX + K - 1;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave index, kept scalar
-  double* wxl = lds + rows * P;                             // flipped taps, zero padded
-  double* wyl = wxl + kpad;
-  for (int e = tid; e < kpad; e += CV_NT) { wxl[e] = g.gx_pad[e]; wyl[e] = g.gy_pad[e]; }
+  // beam = sum over nrank outer products gy[r] (x) gx[r] (1 for an axis-aligned
+  // Gaussian, the leading singular triplets for a rotated one).  With one term
+  // the row-pass output overlays the input tile; with several the tile must
+  // survive, so the intermediate gets LDS of its own.
+  double* wxl = lds + rows * P;                             // [nrank][kpad] flipped taps, zero padded
+  double* wyl = wxl + nrank * kpad;
+  double* tmp = nrank == 1 ? lds : wyl + nrank * kpad;      // [rows][P2]
+  for (int e = tid; e < nrank * kpad; e += CV_NT) { wxl[e] = g.gx_pad[e]; wyl[e] = g.gy_pad[e]; }
   __syncthreads();
   const int nlive = *count;
   constexpr int DW = sizeof(WinDesc) / 4;                   // descriptor dwords
@@ -927,81 +933,86 @@ k_conv_chi2(FitK g, const double* __restrict__ iunif,
     }
     __syncthreads();
 
-    // -- 3. row pass over the rows with emission: tmp[row][x] = sum_u gxf[u] tile[row][x+u]
-    //       wave <-> block of R output columns, lanes <-> rows (odd pitch: conflict-free)
-    double res[MAXR][R];
-#pragma unroll
-    for (int q = 0; q < MAXR; ++q) {
-      const int ridx = q * 64 + lane;
-#pragma unroll
-      for (int r = 0; r < R; ++r) res[q][r] = 0.0;
-      if (q * 64 < nlr && ridx < nlr) {
-        const int rr = s_rowlist[ridx];
-        const double* row = lds + rr * P + wv * R;
-        double win[R];
-#pragma unroll
-        for (int r = 0; r < R - 1; ++r) win[r] = row[r];
-        for (int u0 = 0; u0 < kpad; u0 += R) {
-#pragma unroll
-          for (int qq = 0; qq < R; ++qq) {
-            win[(qq + R - 1) % R] = row[u0 + qq + R - 1];
-            const double wgt = wxl[u0 + qq];
-#pragma unroll
-            for (int r = 0; r < R; ++r)
-              res[q][r] = fma(wgt, win[(r + qq) % R], res[q][r]);
-          }
-        }
-      }
-    }
-    __syncthreads();
-    // rows without emission convolve to zero; the others come from registers
-#pragma unroll
-    for (int q = 0; q < MAXR; ++q) {
-      const int rr = q * 64 + lane;
-      if (rr < rows) {
-        const unsigned long long mw = q == 0 ? m0 : q == 1 ? m1 : q == 2 ? m2 : m3;
-        if (!((mw >> lane) & 1ull)) {
-#pragma unroll
-          for (int r = 0; r < R; ++r) lds[rr * P2 + wv * R + r] = 0.0;
-        }
-      }
-    }
-#pragma unroll
-    for (int q = 0; q < MAXR; ++q) {
-      const int ridx = q * 64 + lane;
-      if (ridx < nlr) {
-        const int rr = s_rowlist[ridx];
-#pragma unroll
-        for (int r = 0; r < R; ++r) lds[rr * P2 + wv * R + r] = res[q][r];
-      }
-    }
-    __syncthreads();
-
-    // -- 4. column pass: out[y][x] = sum_u gyf[u] tmp[y+u][x]; lanes <-> x, waves <-> y blocks
+    // -- 3+4. per beam term: row pass over the rows with emission
+    //         tmp[row][x] = sum_u gxf[u] tile[row][x+u]   (wave <-> R output columns,
+    //         lanes <-> rows; odd pitch: conflict-free), then column pass
+    //         out[y][x] += sum_u gyf[u] tmp[y+u][x]        (lanes <-> x, waves <-> y blocks)
     double acc[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) acc[r] = 0.0;
-    if (wv < TY / R) {
-      const double* col = lds + (wv * R) * P2 + lane;
-      for (int u0 = 0; u0 < kpad; u0 += R) {
-        // rows wv*R+u0 .. +2R-2 feed this tap block: skip it if none holds emission
-        const int ra = wv * R + u0;
-        unsigned long long bits = 0ull;
-        {
-          const int w0 = ra >> 6, sh = ra & 63;
-          const unsigned long long lo = w0 == 0 ? m0 : w0 == 1 ? m1 : w0 == 2 ? m2 : m3;
-          const unsigned long long hi = w0 == 0 ? m1 : w0 == 1 ? m2 : w0 == 2 ? m3 : 0ull;
-          bits = (lo >> sh) | (sh ? (hi << (64 - sh)) : 0ull);
+    for (int rk = 0; rk < nrank; ++rk) {
+      const double* wxr = wxl + rk * kpad;
+      const double* wyr = wyl + rk * kpad;
+      double res[MAXR][R];
+#pragma unroll
+      for (int q = 0; q < MAXR; ++q) {
+        const int ridx = q * 64 + lane;
+#pragma unroll
+        for (int r = 0; r < R; ++r) res[q][r] = 0.0;
+        if (q * 64 < nlr && ridx < nlr) {
+          const int rr = s_rowlist[ridx];
+          const double* row = lds + rr * P + wv * R;
+          double win[R];
+#pragma unroll
+          for (int r = 0; r < R - 1; ++r) win[r] = row[r];
+          for (int u0 = 0; u0 < kpad; u0 += R) {
+#pragma unroll
+            for (int qq = 0; qq < R; ++qq) {
+              win[(qq + R - 1) % R] = row[u0 + qq + R - 1];
+              const double wgt = wxr[u0 + qq];
+#pragma unroll
+              for (int r = 0; r < R; ++r)
+                res[q][r] = fma(wgt, win[(r + qq) % R], res[q][r]);
+            }
+          }
         }
-        if (!(bits & ((1ull << (2 * R - 1)) - 1ull))) continue;
-        double win[2 * R - 1];
+      }
+      __syncthreads();                  // tile reads (overlay) / previous column pass done
+      // rows without emission convolve to zero; the others come from registers
 #pragma unroll
-        for (int r = 0; r < 2 * R - 1; ++r) win[r] = col[(u0 + r) * P2];
+      for (int q = 0; q < MAXR; ++q) {
+        const int rr = q * 64 + lane;
+        if (rr < rows && rk == 0) {
+          const unsigned long long mw = q == 0 ? m0 : q == 1 ? m1 : q == 2 ? m2 : m3;
+          if (!((mw >> lane) & 1ull)) {
 #pragma unroll
-        for (int qq = 0; qq < R; ++qq) {
-          const double wgt = wyl[u0 + qq];
+            for (int r = 0; r < R; ++r) tmp[rr * P2 + wv * R + r] = 0.0;
+          }
+        }
+      }
 #pragma unroll
-          for (int r = 0; r < R; ++r) acc[r] = fma(wgt, win[r + qq], acc[r]);
+      for (int q = 0; q < MAXR; ++q) {
+        const int ridx = q * 64 + lane;
+        if (ridx < nlr) {
+          const int rr = s_rowlist[ridx];
+#pragma unroll
+          for (int r = 0; r < R; ++r) tmp[rr * P2 + wv * R + r] = res[q][r];
+        }
+      }
+      __syncthreads();
+
+      if (wv < TY / R) {
+        const double* col = tmp + (wv * R) * P2 + lane;
+        for (int u0 = 0; u0 < kpad; u0 += R) {
+          // rows wv*R+u0 .. +2R-2 feed this tap block: skip it if none holds emission
+          const int ra = wv * R + u0;
+          unsigned long long bits = 0ull;
+          {
+            const int w0 = ra >> 6, sh = ra & 63;
+            const unsigned long long lo = w0 == 0 ? m0 : w0 == 1 ? m1 : w0 == 2 ? m2 : m3;
+            const unsigned long long hi = w0 == 0 ? m1 : w0 == 1 ? m2 : w0 == 2 ? m3 : 0ull;
+            bits = (lo >> sh) | (sh ? (hi << (64 - sh)) : 0ull);
+          }
+          if (!(bits & ((1ull << (2 * R - 1)) - 1ull))) continue;
+          double win[2 * R - 1];
+#pragma unroll
+          for (int r = 0; r < 2 * R - 1; ++r) win[r] = col[(u0 + r) * P2];
+#pragma unroll
+          for (int qq = 0; qq < R; ++qq) {
+            const double wgt = wyr[u0 + qq];
+#pragma unroll
+            for (int r = 0; r < R; ++r) acc[r] = fma(wgt, win[r + qq], acc[r]);
+          }
         }
       }
     }
@@ -1281,6 +1292,7 @@ struct slamhip_ctx {
   int conv_mode = 0;
   int kpad = 0;
   int sep_variant = 0;     // 0: <64,3>  1: <64,5>  2: <32,4>  -1: none fits
+  int nrank = 1;           // outer-product terms of the beam used by the fused kernel
   size_t sep_lds = 0, c2d_lds = 0, fz_lds = 0;
   hipStream_t stream = nullptr;
   // optional per-kernel HIP-event timing (slamhip_profile_begin/_end)
@@ -1345,6 +1357,61 @@ int dev_upload(slamhip_ctx* c, const T** p, const T* host, size_t count) {
   HIP_TRY(c, hipMemcpy(q, host, count * sizeof(T), hipMemcpyHostToDevice));
   *p = q;
   return SLAMHIP_OK;
+}
+
+// One-sided Jacobi SVD of the K x K beam: B = sum_r sig[r] * U[:,r] (x) V[:,r],
+// singular values in decreasing order.  K <= ~100, run once per fit.
+void beam_svd(const double* B, int K, std::vector<double>& U, std::vector<double>& V,
+              std::vector<double>& sig) {
+  std::vector<double> A(B, B + (size_t)K * K);      // columns get orthogonalised
+  V.assign((size_t)K * K, 0.0);
+  for (int i = 0; i < K; ++i) V[(size_t)i * K + i] = 1.0;
+  for (int sweep = 0; sweep < 60; ++sweep) {
+    double off = 0.0;
+    for (int p = 0; p < K - 1; ++p)
+      for (int q = p + 1; q < K; ++q) {
+        double alpha = 0, beta = 0, gamma = 0;
+        for (int i = 0; i < K; ++i) {
+          const double ap = A[(size_t)i * K + p], aq = A[(size_t)i * K + q];
+          alpha += ap * ap; beta += aq * aq; gamma += ap * aq;
+        }
+        if (gamma == 0.0 || alpha * beta == 0.0) continue;
+        off = std::max(off, std::fabs(gamma) / std::sqrt(alpha * beta));
+        const double zeta = (beta - alpha) / (2.0 * gamma);
+        const double t = (zeta >= 0 ? 1.0 : -1.0) / (std::fabs(zeta) + std::sqrt(1.0 + zeta * zeta));
+        const double cs = 1.0 / std::sqrt(1.0 + t * t), sn = cs * t;
+        for (int i = 0; i < K; ++i) {
+          const double ap = A[(size_t)i * K + p], aq = A[(size_t)i * K + q];
+          A[(size_t)i * K + p] = cs * ap - sn * aq;
+          A[(size_t)i * K + q] = sn * ap + cs * aq;
+          const double vp = V[(size_t)i * K + p], vq = V[(size_t)i * K + q];
+          V[(size_t)i * K + p] = cs * vp - sn * vq;
+          V[(size_t)i * K + q] = sn * vp + cs * vq;
+        }
+      }
+    if (off < 1e-15) break;
+  }
+  std::vector<int> order(K);
+  std::vector<double> nrm(K);
+  for (int j = 0; j < K; ++j) {
+    double s2 = 0;
+    for (int i = 0; i < K; ++i) s2 += A[(size_t)i * K + j] * A[(size_t)i * K + j];
+    nrm[j] = std::sqrt(s2);
+    order[j] = j;
+  }
+  std::sort(order.begin(), order.end(), [&](int a, int b) { return nrm[a] > nrm[b]; });
+  U.assign((size_t)K * K, 0.0);
+  std::vector<double> Vs((size_t)K * K);
+  sig.assign(K, 0.0);
+  for (int r = 0; r < K; ++r) {
+    const int j = order[r];
+    sig[r] = nrm[j];
+    for (int i = 0; i < K; ++i) {
+      U[(size_t)i * K + r] = nrm[j] > 0 ? A[(size_t)i * K + j] / nrm[j] : 0.0;
+      Vs[(size_t)i * K + r] = V[(size_t)i * K + j];
+    }
+  }
+  V.swap(Vs);
 }
 
 // Samples that survive the layer merge (:469-472), listed per output pixel.
@@ -1476,7 +1543,7 @@ int run_group(slamhip_ctx* c, const double* d_params, int nw, double* d_chi2,
       hipLaunchKernelGGL((k_conv_chi2<TY_, MR_>), gz, dim3(CV_NT), c->fz_lds, st, c->k,   \
                          c->d_iunif, c->d_cellx, c->d_fracx, c->d_celly, c->d_fracy,       \
                          c->d_livelist, c->d_livecount, (int)c->fz_grid.x, (int)c->fz_grid.y, \
-                         c->d_partial, c->kpad)
+                         c->d_partial, c->kpad, c->nrank)
       switch (c->sep_variant) {
         case 0: SLAM_FUSED(64, 2); break;
         case 1: SLAM_FUSED(64, 3); break;
@@ -1617,11 +1684,36 @@ int slamhip_create(const slamhip_desc* d, slamhip_ctx** out) {
   c->separable = (peak != 0.0 && worst <= 1e-14 * std::fabs(peak)) ? 1 : 0;
   c->kpad = (K + CONV_R - 1) / CONV_R * CONV_R;
   std::vector<double> gx(c->kpad, 0.0), gy(c->kpad, 0.0);
-  if (c->separable)
+  c->nrank = 1;
+  if (c->separable) {
     for (int u = 0; u < K; ++u) {   // flipped: correlation taps
       gx[u] = d->gaussbeam[(size_t)cc * K + (K - 1 - u)];
       gy[u] = d->gaussbeam[(size_t)(K - 1 - u) * K + cc] / peak;
     }
+  } else if (K > 1) {
+    // rotated beam: leading singular triplets until the dropped tail is below
+    // 1e-13 of the largest (a Gaussian's singular values fall ~x7 per term)
+    std::vector<double> U, V, sig;
+    beam_svd(d->gaussbeam, K, U, V, sig);
+    int R = 0;
+    double tail = 0.0;
+    for (int r = K - 1; r >= 0; --r) {
+      if (tail + sig[r] > 1e-13 * sig[0]) { R = r + 1; break; }
+      tail += sig[r];
+    }
+    if (R >= 1 && R <= MAX_RANK) {
+      c->nrank = R;
+      gx.assign((size_t)R * c->kpad, 0.0);
+      gy.assign((size_t)R * c->kpad, 0.0);
+      for (int r = 0; r < R; ++r)
+        for (int u = 0; u < K; ++u) {
+          gx[(size_t)r * c->kpad + u] = V[(size_t)(K - 1 - u) * K + r];
+          gy[(size_t)r * c->kpad + u] = sig[r] * U[(size_t)(K - 1 - u) * K + r];
+        }
+    } else {
+      c->nrank = 0;                  // not factorisable cheaply: direct 2-D taps only
+    }
+  }
   c->sep_variant = -1;
   if (sep_lds_bytes(64, c->kpad) <= 80 * 1024 && (64 + c->kpad - 1) * (CONV_TX / CONV_R) <= 3 * 256) {
     c->sep_variant = 0; c->sep_lds = sep_lds_bytes(64, c->kpad);
@@ -1637,14 +1729,20 @@ int slamhip_create(const slamhip_desc* d, slamhip_ctx** out) {
                                          : (const void*)k_conv_sep<32, 4>;
     HIP_TRY(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->sep_lds));
   }
-  c->fz_lds = c->sep_lds + 2 * (size_t)c->kpad * sizeof(double);
-  if (c->fz_lds > 48 * 1024 && c->sep_variant >= 0) {
+  c->fz_lds = c->sep_lds + 2 * (size_t)std::max(c->nrank, 1) * c->kpad * sizeof(double);
+  if (c->nrank > 1 && c->sep_variant >= 0) {
+    // several beam terms: the row-pass intermediate cannot overlay the tile
+    const int ty = c->sep_variant == 2 ? 32 : 64;
+    c->fz_lds += (size_t)(ty + c->kpad - 1) * (CONV_TX + 1) * sizeof(double);
+    if (c->fz_lds > 156 * 1024) c->nrank = 0;
+  }
+  if (c->nrank >= 1 && c->fz_lds > 48 * 1024 && c->sep_variant >= 0) {
     const void* fz = c->sep_variant == 0 ? (const void*)k_conv_chi2<64, 2>
                    : c->sep_variant == 1 ? (const void*)k_conv_chi2<64, 3>
                                          : (const void*)k_conv_chi2<32, 2>;
     HIP_TRY(c, hipFuncSetAttribute(fz, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->fz_lds));
   }
-  c->fused = c->separable && c->sep_variant >= 0;
+  c->fused = c->nrank >= 1 && c->sep_variant >= 0;
   {
     const int ty = c->sep_variant == 2 ? 32 : 64;
     c->fz_sx = CONV_TX - 1;
@@ -1772,6 +1870,11 @@ int slamhip_profile_end(slamhip_ctx* c, double* total_ms, int64_t* launches) {
   }
   c->spans.clear();
   return rc;
+}
+
+int slamhip_beam_rank(slamhip_ctx* c) {
+  if (!c) return SLAMHIP_ERR_ARG;
+  return c->fused ? c->nrank : 0;
 }
 
 int slamhip_set_conv_mode(slamhip_ctx* c, int mode) {

@@ -77,6 +77,7 @@ class HipLikelihood:
                                C.byref(sep))
         self.nleaf, self.walkers_per_group = nleaf.value, wg.value
         self.separable_beam = bool(sep.value)
+        self.beam_rank = int(self._lib.slamhip_beam_rank(self._ctx))
 
     # -- plumbing ----------------------------------------------------------
     def _errmsg(self):
