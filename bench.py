@@ -105,10 +105,11 @@ def main():
         dom = max(alg, key=lambda k: kern.get(k, (0, 0))[0])
         ms, cnt = kern[dom]
         achieved = alg[dom] * evals_rank / (ms * 1e-3)
+        traffic, traffic_note = measured_traffic(dom, args, eng)
         roofline = {
             'bound': 'hbm', 'kernel': dom,
             'achieved': achieved / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
-            'frac': achieved / HBM_PEAK, 'traffic': None,
+            'frac': achieved / HBM_PEAK, 'traffic': traffic, 'traffic_source': traffic_note,
             'bytes_per_launch': alg[dom] * evals_rank / cnt,
             'ms_per_launch': ms / cnt, 'launches': cnt,
             'pipeline': {'bytes_per_eval': bytes_eval,
@@ -137,6 +138,31 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def measured_traffic(kernel, args, eng):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes
+    (FETCH_SIZE and WRITE_SIZE in separate runs, FETCH_SIZE doubled as
+    MI355X_MICROARCH.md's HBM section prescribes for gfx950; calibration on
+    kernels of known size is in DESIGN.md).  bench.py itself cannot read the
+    counters, so this is the figure of the profiled run of the same command;
+    null if no matching profile is committed."""
+    path = os.path.join(ROOT, 'profiles', 'r1_traffic.json')
+    try:
+        t = json.load(open(path))
+    except Exception:
+        return None, None
+    meta = t.get('_meta', {})
+    if (meta.get('config') != args.config or meta.get('walkers_per_launch') != eng.walkers_per_group
+            or meta.get('bpa') != args.bpa):
+        return None, None
+    names = {'k_conv': 'k_conv_chi2', 'k_profile': 'k_profile', 'k_surface': 'k_surface',
+             'k_regrid': 'k_regrid'}
+    for k, v in t.items():
+        if k.startswith(names.get(kernel, kernel)):
+            return (2.0 * v['fetch_bytes_per_launch_max'] + v['write_bytes_per_launch_max'],
+                    'profiles/r1_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, max over launches)')
+    return None, None
 
 
 def cpu_baseline(fit, P, chi2_gpu, nevals):

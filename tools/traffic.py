@@ -49,8 +49,15 @@ def main():
                   'fetch_bytes_per_launch_max': max(f) if f else 0.0,
                   'write_bytes_per_launch': sum(w) / max(len(w), 1),
                   'write_bytes_per_launch_max': max(w) if w else 0.0}
+    b = json.loads(bench)
+    out['_meta'] = {'config': 'C3' if '512x512x128' in b['metric'] else b['metric'].split()[-1],
+                    'walkers_per_launch': b['config']['walkers_per_launch'],
+                    'bpa': 0.0 if 'bpa=0 ' in b['config']['workload'] else None,
+                    'fetch_correction': 'FETCH_SIZE x2 (gfx950 counts 64 B per 128-B request)'}
     json.dump(out, open(f'profiles/{tag}_traffic.json', 'w'), indent=1)
     for k, v in out.items():
+        if k.startswith('_'):
+            continue
         print(f"{k:28s} n={v['launches']:4d} fetch_raw={v['fetch_bytes_per_launch_max']/1e6:10.2f} MB"
               f"  write={v['write_bytes_per_launch_max']/1e6:10.2f} MB (max per launch)")
 
