@@ -1,26 +1,35 @@
-"""Build libslamhip.so (gfx950) in-tree with hipcc.  `python -m slam_amd.build`."""
+"""Build libslamhip.so and libslampv.so (gfx950) in-tree with hipcc.
+`python -m slam_amd.build`."""
 import os
 import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-SRC = os.path.join(HERE, 'csrc', 'slamhip.hip')
-OUT = os.path.join(HERE, 'libslamhip.so')
+# (source, header, output)
+TARGETS = [
+    (os.path.join(HERE, 'csrc', 'slamhip.hip'), os.path.join(ROOT, 'include', 'slamhip.h'),
+     os.path.join(HERE, 'libslamhip.so')),
+    (os.path.join(HERE, 'csrc', 'slampv.hip'), os.path.join(ROOT, 'include', 'slampv.h'),
+     os.path.join(HERE, 'libslampv.so')),
+]
+SRC, _, OUT = TARGETS[0]
 
 
 def build(force=False, verbose=True):
-    deps = [SRC, os.path.join(ROOT, 'include', 'slamhip.h')]
-    if (not force and os.path.exists(OUT)
-            and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in deps)):
-        return OUT
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-    cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared',
-           '-ffp-contract=off', '-I', os.path.join(ROOT, 'include'), SRC, '-o', OUT]
-    if verbose:
-        print(' '.join(cmd), flush=True)
-    subprocess.check_call(cmd)
-    return OUT
+    outs = []
+    for src, hdr, out in TARGETS:
+        outs.append(out)
+        if (not force and os.path.exists(out)
+                and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in (src, hdr))):
+            continue
+        cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared',
+               '-ffp-contract=off', '-I', os.path.join(ROOT, 'include'), src, '-o', out]
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return outs[0]
 
 
 if __name__ == '__main__':

@@ -128,6 +128,65 @@ class ReadFits:
         self.cubefits, self.dist, self.vsys = cubefits, dist, vsys
         return {'x': x, 'y': y, 'v': v, 'data': d, 'header': h, 'sigma': sigma}
 
+    def read_pvfits(self, pvfits: str,
+                    dist: float = 1, vsys: float = 0,
+                    xmin: float | None = None, xmax: float | None = None,
+                    vmin: float | None = None, vmax: float | None = None,
+                    xskip: int = 1,
+                    sigma: float | None = None) -> dict:
+        """Read a position-velocity diagram: offset axis in au (ascending),
+        velocity in km s^-1 relative to `vsys`, cropped to the given limits
+        (reference utils.py:279-352)."""
+        d, h = fitsio.read_primary(pvfits)
+        d = np.squeeze(d)
+        h = dict(h)
+        if sigma is None:
+            sigma = np.mean([np.std(d[:2, 10:-10]), np.std(d[-2:, 10:-10]),
+                             np.std(d[2:-2, :10]), np.std(d[2:-2, -10:])])
+            print(f'sigma = {sigma:.3e}')
+        x = (np.arange(h['NAXIS1']) - h['CRPIX1'] + 1) * h['CDELT1']
+        v = (np.arange(h['NAXIS2']) - h['CRPIX2'] + 1) * h['CDELT2']
+        crpix = int(h['CRPIX1']) - 1
+        start = crpix % xskip
+        x, d = x[start::xskip], d[:, start::xskip]
+        h['CRPIX1'] = (crpix - start) // xskip + 1
+        h['CDELT1'] = h['CDELT1'] * xskip
+        v = v + h['CRVAL2']
+        x = (x + h['CRVAL1']) * dist  # au
+        if h.get('CUNIT2') == 'Hz':
+            if 'RESTFRQ' in h:
+                restfreq = h['RESTFRQ']
+            elif 'RESTFREQ' in h:
+                restfreq = h['RESTFREQ']
+            else:
+                restfreq = np.mean(v)
+                print('No rest frequency found. The middle frequency adopted.')
+            v = (1. - v / restfreq) * _C_SI / 1.e3 - vsys  # km/s
+        elif h.get('CUNIT2') == 'm/s':
+            v = v * 1e-3 - vsys
+        i0 = 0 if xmin is None else np.argmin(np.abs(x - xmin))
+        i1 = len(x) - 1 if xmax is None else np.argmin(np.abs(x - xmax))
+        k0 = 0 if vmin is None else np.argmin(np.abs(v - vmin))
+        k1 = len(v) - 1 if vmax is None else np.argmin(np.abs(v - vmax))
+        x, v = x[i0:i1 + 1], v[k0:k1 + 1]
+        d = d[k0:k1 + 1, i0:i1 + 1]
+        self.offpix = (i0, k0)
+        dx, dv = x[1] - x[0], v[1] - v[0]
+        if 'BMAJ' in h:
+            bmaj = h['BMAJ'] * 3600. * dist  # au
+            bmin = h['BMIN'] * 3600. * dist  # au
+            bpa = h['BPA']  # deg
+        else:
+            bmaj, bmin, bpa = dx, dx, 0
+            print('No valid beam in the FITS file.')
+        self.x, self.dx, self.nx = x, dx, len(x)
+        self.v, self.dv, self.nv = v, dv, len(v)
+        self.data, self.header, self.sigma = d, h, sigma
+        self.bmaj, self.bmin, self.bpa = bmaj, bmin, bpa
+        self.beam = np.array([bmaj, bmin, bpa])
+        self.pvfits, self.dist, self.vsys = pvfits, dist, vsys
+        return {'x': x, 'v': v, 'data': d, 'header': h, 'sigma': sigma}
+
 
 # ---------------------------------------------------------------------------
 # Sampler
