@@ -30,7 +30,9 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--config', default='C3', choices=['C2', 'C3', 'C4'])
+    ap.add_argument('--config', default='C3', choices=['C2', 'C3', 'C4', 'P5'],
+                    help='C2-C4: channelfit SYN-v1 cubes; P5: pvfitting mock-PV likelihood on the '
+                         'reference test PV diagrams (BASELINE config 5)')
     ap.add_argument('--walkers', type=int, default=1024, help='walkers per GPU per step')
     ap.add_argument('--bpa', type=float, default=0.0, help='beam position angle [deg]; 0 = separable')
     ap.add_argument('--cpu-evals', type=int, default=1,
@@ -50,6 +52,11 @@ def main():
 
     from slam_amd import synth
     from slam_amd.sharding import ShardedLikelihood
+    if args.config == 'P5':
+        run_pv(args, rank, world, torch, dist)
+        if world > 1:
+            dist.destroy_process_group()
+        return
     fit = synth.make_fit(args.config, bpa=args.bpa)
     eng = fit.engine
     nw_total = args.walkers * world
@@ -138,6 +145,91 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def run_pv(args, rank, world, torch, dist):
+    """pvfitting's mock-PV likelihood: the example's grid
+    (59 x 21 x 287 parent, six 2x nestings) and the reference's test PV diagrams
+    (tests/golden/pvfit_example_fit.npz holds them as data), `--walkers` parameter
+    vectors per GPU per step in the example's priors."""
+    from slam_amd import synth
+    from slam_amd.sharding import ShardedLikelihood
+    mpvd, kw = synth.make_pvfit()
+    nw_total = args.walkers * world
+    Q = synth.pv_walkers(nw_total)
+    eng = mpvd.engine(Q[0, 1], kw['incl'], kw['linewidth'], kw['rin'], kw['rout'])
+    sharded = ShardedLikelihood(eng.lnprob_batch_torch, device='cuda', nparam=6)
+    Qd = torch.as_tensor(Q, device='cuda') if rank == 0 else None
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        lnp = sharded.chi2(Qd, nw_total)
+    barrier()
+    eng.profile_begin()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        lnp = sharded.chi2(Qd, nw_total)
+    barrier()
+    dt = time.perf_counter() - t0
+    kern = eng.profile_end()
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    lnp = lnp.cpu().numpy()
+    if rank != 0:
+        return
+    evals_rank = args.walkers * args.steps
+    nv = eng.nv
+    ncol = sum(nx * ny for nx, ny, _ in eng.shapes)
+    # algorithmic bytes per evaluation of k_pv_tau: every live cell's constants
+    # (int32 + 4 doubles) and its 5 table entries once, plus one column-sum
+    # image per level and axis
+    alg_tau = eng.live_cells * (36 + 40) + 2 * nv * ncol * 8
+    total_ms = sum(v[0] for v in kern.values())
+    per_kernel = {n: {'ms_per_launch': ms / c, 'launches': c, 'ms_per_eval': ms / evals_rank,
+                      'share': ms / total_ms} for n, (ms, c) in kern.items() if c}
+    ms, cnt = kern['k_pv_tau']
+    achieved = alg_tau * evals_rank / (ms * 1e-3)
+    out = {
+        'metric': 'walker lnprob evals/sec (whole node), pvfitting mock-PV on test.pvfitting.*.fits',
+        'value': nw_total * args.steps / dt, 'unit': 'evals/s', 'n_gpus': world,
+        'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64',
+        'data': 'reference test PV diagrams (as golden data) + synthetic walkers',
+        'config': {'workload': f'P5: mock-PV likelihood, parent grid {eng.shapes[0]}, '
+                               f'{len(eng.shapes)} levels, {eng.live_cells} live cells (both axes), '
+                               f'nv={nv}, {args.walkers} walkers per GPU per step',
+                   'walkers_per_gpu': args.walkers, 'walkers_per_launch': eng.walkers_per_group,
+                   'lnp_checksum': float(np.sum(lnp))},
+        'roofline': {'bound': 'hbm', 'kernel': 'k_pv_tau', 'achieved': achieved / 1e9,
+                     'peak': HBM_PEAK / 1e9, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK,
+                     'traffic': None, 'bytes_per_launch': alg_tau * evals_rank / cnt,
+                     'ms_per_launch': ms / cnt, 'launches': cnt, 'per_kernel': per_kernel},
+    }
+    if world == 1 and args.cpu_evals > 0:
+        out['cpu_baseline'] = cpu_baseline_pv(kw, Q, lnp, max(args.cpu_evals, 8))
+    print(json.dumps(out), flush=True)
+
+
+def cpu_baseline_pv(kw, Q, lnp_gpu, nevals):
+    """The numpy oracle of the reference's mock-PV path, one process."""
+    from oracle import pvfitting_oracle as orc
+    from slam_amd import synth
+    s, obs = synth.make_pvfit_oracle(orc, rc_first=Q[0, 1])
+    orc.lnprob(s, obs, Q[0])                         # tables / first-call work untimed
+    t0 = time.perf_counter()
+    ref = np.array([orc.lnprob(s, obs, Q[i]) for i in range(nevals)])
+    dt = time.perf_counter() - t0
+    err = float(np.max(np.abs(ref - lnp_gpu[:nevals]) / np.abs(ref)))
+    return {'value': nevals / dt, 'unit': 'evals/s', 'cores': 1, 'kind': 'port',
+            'sample': f'first {nevals} of the {len(Q)} walkers, oracle/pvfitting_oracle.py '
+                      '(numpy+scipy, single process)',
+            'seconds': dt, 'max_rel_err_vs_gpu': err}
 
 
 def measured_traffic(kernel, args, eng):

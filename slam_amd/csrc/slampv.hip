@@ -35,7 +35,9 @@
 
 namespace {
 
-constexpr int ZCHUNK = 48;      // longest z run one lane walks
+constexpr int ZCHUNK = 72;      // longest z run one lane walks
+constexpr int ZU = 8;           // cells in flight per lane
+constexpr int TAU_WAVES = 4;    // walkers (waves) per k_pv_tau workgroup
 constexpr int MAX_LEVELS = 12;
 constexpr int NT = 256;         // threads of the small kernels
 
@@ -85,10 +87,29 @@ __device__ __forceinline__ double wave_max(double v) {
 
 // ---------------------------------------------------------------------------
 __global__ void k_pv_prep(PvK k, const double* __restrict__ params, int nw,
-                          WalkerPV* __restrict__ wk, unsigned long long* __restrict__ tmaxbits) {
+                          WalkerPV* __restrict__ wk, unsigned long long* __restrict__ tmaxbits,
+                          int* __restrict__ order) {
   const int w = blockIdx.x * blockDim.x + threadIdx.x;
   if (w >= nw) return;
   const double* p = params + (size_t)w * SLAMPV_NPARAM;
+  // position of this walker in the batch sorted by Rc (ties by index): walkers
+  // with neighbouring Rc read the same table lines, k_pv_tau runs them together
+  {
+    const double rc = p[1];
+    int rank = 0;
+    for (int i = 0; i < nw; ++i) {
+      const double ri = params[(size_t)i * SLAMPV_NPARAM + 1];
+      rank += (ri < rc) || (ri == rc && i < w) || (ri == ri && rc != rc);
+    }
+    if (rc != rc) {           // NaN keys go last, by index
+      rank = 0;
+      for (int i = 0; i < nw; ++i) {
+        const double ri = params[(size_t)i * SLAMPV_NPARAM + 1];
+        rank += (ri == ri) || i < w;
+      }
+    }
+    order[rank] = w;
+  }
   WalkerPV o;
   o.shift = log(p[1]) / k.dlnr;                                   // precalculation.py:184
   o.vunit = sqrt(k.g_si * p[0] * k.m_sun / p[1] / k.au_m) * 1e-3;  // mockpvd.py:204
@@ -104,22 +125,33 @@ __global__ void k_pv_prep(PvK k, const double* __restrict__ params, int nw,
 // ---------------------------------------------------------------------------
 // One wave = 64 neighbouring columns of one (axis, level, z chunk).  A lane
 // walks its column along z, keeps the running sum of the channel it is in and
-// flushes it to its private LDS histogram when the channel changes.
-__global__ __launch_bounds__(64) void k_pv_tau(PvK k, const Task* __restrict__ tasks,
+// adds it to its own column of the chunk's image when the channel changes.
+__global__ __launch_bounds__(64 * TAU_WAVES) void k_pv_tau(PvK k, const Task* __restrict__ tasks,
                                                const WalkerPV* __restrict__ wk,
+                                               const int* __restrict__ order, int nw,
                                                double* __restrict__ own) {
   extern __shared__ double sh[];
   const int nv = k.nv;
-  double* s_edge = sh;                       // [nv+1] (+pad)
-  double* s_hist = sh + ((nv + 2) & ~1);     // [nv][64]
-  const int lane = threadIdx.x;
-  const Task t = tasks[blockIdx.x];
-  const int w = blockIdx.y;
+  double* s_edge = sh;                       // [nv+1]
+  const int lane = threadIdx.x & 63;
+  for (int i = threadIdx.x; i <= nv; i += 64 * TAU_WAVES) s_edge[i] = k.vedge[i];
+  __syncthreads();
+  // The TAU_WAVES waves of a workgroup take the same columns for TAU_WAVES
+  // walkers that are neighbours in the Rc-sorted batch: they share one CU's L1
+  // and gather neighbouring table columns, and the cell constants of a task are
+  // fetched from HBM once for all walkers (L2).  Workgroups go round-robin over
+  // the 8 XCDs, each with its own L2: XCD x takes the x-th eighth of the sorted
+  // batch.
+  const Task t = tasks[blockIdx.y];
+  const int ngroup = (nw + TAU_WAVES - 1) / TAU_WAVES;
+  const int per = (ngroup + 7) >> 3;
+  const int b = blockIdx.x;
+  const int grp = ngroup < 16 ? b : (b & 7) * per + (b >> 3);
+  const int slot = grp * TAU_WAVES + (threadIdx.x >> 6);
+  if (grp >= ngroup || slot >= nw) return;   // whole waves leave, after the only barrier
+  const int w = order[slot];
   const LevelK& L = k.lv[t.level];
   const WalkerPV q = wk[w];
-  for (int i = lane; i <= nv; i += 64) s_edge[i] = k.vedge[i];
-  for (int i = 0; i < nv; ++i) s_hist[i * 64 + lane] = 0.0;
-  __syncthreads();
   const int col = t.col0 + lane;
   const bool active = col < L.ncol;
   const int z0 = t.chunk * L.zlen;
@@ -133,45 +165,67 @@ __global__ __launch_bounds__(64) void k_pv_tau(PvK k, const Task* __restrict__ t
     const double* __restrict__ et = L.et[t.axis];
     const double* __restrict__ ep = L.ep[t.axis];
     const double jmax = (double)(k.nr - 1);
+    const double nvp1 = (double)nv + 1.0;
+    // the lane's own column of this chunk's image: cleared, then updated in
+    // place whenever the running channel changes (same lane, program order)
+    double* __restrict__ o = own + (size_t)w * k.own_stride + L.own_off[t.axis]
+        + (size_t)t.chunk * nv * L.ncol + col;
+    for (int v = 0; v < nv; ++v) o[(size_t)v * L.ncol] = 0.0;
     int cur = -1;
     double acc = 0.0;
-    size_t c = (size_t)z0 * L.ncol + col;
-    for (int z = z0; z < z1; ++z, c += L.ncol) {
-      const int i = it[c];
-      if (i < 0) continue;
-      double j = jo[c] - q.shift;
-      j = fmin(fmax(j, 0.0), jmax);           // NaN -> 0, like nothing the prior lets through
-      const int jj = (int)j;
-      const double* e = k.table + ((size_t)i * k.nr + jj) * 8;
-      const double2 a = *reinterpret_cast<const double2*>(e);       // rho_env, rho_disk
-      const double2 b = *reinterpret_cast<const double2*>(e + 2);   // vr_env, vt_env
-      const double vp = e[4];
-      const double rho = a.x + a.y * q.frho;
-      const double vr = b.x * q.alpha;
-      double vl = vr * er[c] + b.y * et[c];
-      vl = vl + vp * ep[c];
-      vl = vl * q.vunit;
-      if (rho == 0.0) continue;               // adds nothing to any channel
-      // channel: vedge[b] <= vl < vedge[b+1], decided on the stored edges
-      double fb = (vl - e0) * inv_dv;
-      if (!(fb >= -1.0 && fb <= (double)nv + 1.0)) continue;        // also NaN
-      int bn = (int)floor(fb);
-      bn = min(max(bn, 0), nv - 1);
-      while (bn > 0 && vl < s_edge[bn]) --bn;
-      while (bn < nv - 1 && vl >= s_edge[bn + 1]) ++bn;
-      if (!(s_edge[bn] <= vl && vl < s_edge[bn + 1])) continue;    // outside every channel
-      if (bn != cur) {
-        if (cur >= 0) s_hist[cur * 64 + lane] += acc;
-        cur = bn;
-        acc = rho;
-      } else {
-        acc += rho;
+    // ZU cells per trip: their constants and table lines are requested
+    // together so that the dependent gathers overlap
+    for (int z = z0; z < z1; z += ZU) {
+      int ci[ZU];
+      double cj[ZU], cr[ZU], ct[ZU], cp[ZU];
+#pragma unroll
+      for (int u = 0; u < ZU; ++u) {
+        const int zz = min(z + u, z1 - 1);
+        const size_t c = (size_t)zz * L.ncol + col;
+        ci[u] = (z + u < z1) ? it[c] : -1;
+        cj[u] = jo[c];
+        cr[u] = er[c];
+        ct[u] = et[c];
+        cp[u] = ep[c];
+      }
+      double2 ta[ZU], tb[ZU];
+      double tv[ZU];
+#pragma unroll
+      for (int u = 0; u < ZU; ++u) {
+        double j = cj[u] - q.shift;
+        j = fmin(fmax(j, 0.0), jmax);           // NaN -> 0; the prior lets no such Rc through
+        const double* e = k.table + ((size_t)max(ci[u], 0) * k.nr + (int)j) * 8;
+        ta[u] = *reinterpret_cast<const double2*>(e);       // rho_env, rho_disk
+        tb[u] = *reinterpret_cast<const double2*>(e + 2);   // vr_env, vt_env
+        tv[u] = e[4];                                       // vp_env + vp_disk
+      }
+#pragma unroll
+      for (int u = 0; u < ZU; ++u) {
+        if (ci[u] < 0) continue;
+        const double rho = ta[u].x + ta[u].y * q.frho;
+        if (rho == 0.0) continue;               // adds nothing to any channel
+        const double vr = tb[u].x * q.alpha;
+        double vl = vr * cr[u] + tb[u].y * ct[u];
+        vl = vl + tv[u] * cp[u];
+        vl = vl * q.vunit;
+        // channel: vedge[b] <= vl < vedge[b+1], decided on the stored edges
+        const double fb = (vl - e0) * inv_dv;
+        if (!(fb >= -1.0 && fb <= nvp1)) continue;          // also NaN
+        int bn = (int)floor(fb);
+        bn = min(max(bn, 0), nv - 1);
+        while (bn > 0 && vl < s_edge[bn]) --bn;
+        while (bn < nv - 1 && vl >= s_edge[bn + 1]) ++bn;
+        if (!(s_edge[bn] <= vl && vl < s_edge[bn + 1])) continue;   // outside every channel
+        if (bn != cur) {
+          if (cur >= 0) o[(size_t)cur * L.ncol] += acc;
+          cur = bn;
+          acc = rho;
+        } else {
+          acc += rho;
+        }
       }
     }
-    if (cur >= 0) s_hist[cur * 64 + lane] += acc;
-    double* o = own + (size_t)w * k.own_stride + L.own_off[t.axis]
-        + (size_t)t.chunk * nv * L.ncol + col;
-    for (int v = 0; v < nv; ++v) o[(size_t)v * L.ncol] = s_hist[v * 64 + lane];
+    if (cur >= 0) o[(size_t)cur * L.ncol] += acc;
   }
 }
 
@@ -455,6 +509,7 @@ struct slampv_ctx {
   double* d_lnp = nullptr;
   double* d_stats = nullptr;
   unsigned long long* d_tmax = nullptr;
+  int* d_order = nullptr;
   size_t lds_tau = 0, lds_nest = 0, lds_cut = 0;
   hipStream_t stream = nullptr;
   bool profiling = false;
@@ -563,12 +618,14 @@ int run_group(slampv_ctx* c, const double* d_params, int nw, double* d_lnp, doub
   {
     Timed t(c, PK_PREP, st);
     hipLaunchKernelGGL(k_pv_prep, dim3((nw + 63) / 64), dim3(64), 0, st, k, d_params, nw, c->d_wk,
-                       c->d_tmax);
+                       c->d_tmax, c->d_order);
   }
   {
     Timed t(c, PK_TAU, st);
-    hipLaunchKernelGGL(k_pv_tau, dim3(c->ntask, nw), dim3(64), c->lds_tau, st, k, c->d_tasks,
-                       c->d_wk, c->d_own);
+    const int ngroup = (nw + TAU_WAVES - 1) / TAU_WAVES;
+    const int gx = ngroup < 16 ? ngroup : ((ngroup + 7) >> 3) << 3;
+    hipLaunchKernelGGL(k_pv_tau, dim3(gx, c->ntask), dim3(64 * TAU_WAVES), c->lds_tau, st, k, c->d_tasks,
+                       c->d_wk, c->d_order, nw, c->d_own);
   }
   {
     Timed t(c, PK_NEST, st);
@@ -692,13 +749,15 @@ int slampv_create(const slampv_desc* d, slampv_ctx** out) {
   }
   k.own_stride = off;
   c->ntask = (int)tasks.size();
+  if (c->ntask > 65535)
+    return fail(c, SLAMPV_ERR_ARG, "%d column tasks per walker exceed the grid limit", c->ntask);
   {
     const Task* dt = nullptr;
     if ((rc = dev_upload(c, &dt, tasks.data(), tasks.size()))) return rc;
     c->d_tasks = const_cast<Task*>(dt);
   }
   // LDS budgets
-  c->lds_tau = ((size_t)((d->nv + 2) & ~1) + (size_t)d->nv * 64) * sizeof(double);
+  c->lds_tau = (size_t)(d->nv + 2) * sizeof(double);
   c->lds_nest = (size_t)2 * k.maxpix * sizeof(double);
   c->lds_cut = ((size_t)k.npix0 * (k.has_beam ? 2 : 1) + NT + k.nx0) * sizeof(double);
   const size_t lds_cap = 150 * 1024;
@@ -731,6 +790,7 @@ int slampv_create(const slampv_desc* d, slampv_ctx** out) {
   if ((rc = dev_alloc(c, &c->d_lnp, (size_t)wg))) return rc;
   if ((rc = dev_alloc(c, &c->d_stats, (size_t)wg * 6))) return rc;
   if ((rc = dev_alloc(c, &c->d_tmax, (size_t)wg * 2))) return rc;
+  if ((rc = dev_alloc(c, &c->d_order, (size_t)wg))) return rc;
   c->wgroup = wg;
   return SLAMPV_OK;
 }

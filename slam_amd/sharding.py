@@ -1,7 +1,8 @@
 """Walker sharding across GPUs: one process per GPU (`torch.distributed`;
 backend "nccl" is RCCL over xGMI on ROCm, "gloo" on CPU for tests).
 
-Walkers are independent (each chi2 depends only on its 13 parameters and on
+Walkers are independent (each chi2 depends only on its own parameters -- 13 for channelfit, 6 for
+the mock-PV likelihood -- and on
 read-only per-fit data replicated on every GPU), so the data path needs no
 collective: the batch is handed out in contiguous blocks and the chi-square
 values are gathered back.  The result is bit-identical for any number of GPUs.
@@ -30,7 +31,8 @@ class ShardedLikelihood:
     chi2 vector back.
     """
 
-    def __init__(self, local_chi2, device='cuda', group=None):
+    def __init__(self, local_chi2, device='cuda', group=None, nparam=13):
+        self.nparam = nparam
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
@@ -53,7 +55,7 @@ class ShardedLikelihood:
                                  if not torch.is_tensor(P) else P,
                                  dtype=torch.float64).to(self.device)
         else:
-            Pt = torch.empty((nw, 13), dtype=torch.float64, device=self.device)
+            Pt = torch.empty((nw, self.nparam), dtype=torch.float64, device=self.device)
         if self.world > 1:
             dist.broadcast(Pt, src=0, group=self.group)          # <= 13*8 B per walker
         counts, offs = partition(nw, self.world)

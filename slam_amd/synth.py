@@ -83,3 +83,74 @@ def bytes_per_eval(fit, itemsize=8):
     write Iunif; read Iunif + write Iconv; read Iconv + read data."""
     e = fit.engine
     return itemsize * e.nv * (4 * e.nneed**2 + e.nx * e.ny)
+
+
+# ---------------------------------------------------------------------------
+# P5: pvfitting's mock-PV likelihood on the reference's test PV diagrams.  The
+# diagrams and axes travel as data in tests/golden/pvfit_example_fit.npz (the
+# FITS files themselves stay in the reference).
+# ---------------------------------------------------------------------------
+PV_EXAMPLE = dict(incl=85., linewidth=None, rin=1., vmask=(-0.3, 0.3), zmax=1000.,
+                  nnest=[2] * 6, reslim=10, signmajor=-1, signminor=1,
+                  pa_major=2.0 - 180, pa_minor=92.0 - 180)
+
+
+def _pv_example_data():
+    import os
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    f = np.load(os.path.join(here, 'tests', 'golden', 'pvfit_example_fit.npz'))
+    x, v = f['obs_x'], f['obs_v']
+    dx = x[1] - x[0]
+    nz = int(PV_EXAMPLE['zmax'] / dx + 0.5)
+    z = (np.arange(2 * nz + 1) - nz) * dx
+    beam = f['obs_beam']
+    vv = np.meshgrid(x, v)[1]
+    hide = (PV_EXAMPLE['vmask'][0] < vv) * (vv < PV_EXAMPLE['vmask'][1])
+    major = np.where(hide, np.nan, f['obs_major'].astype(float))
+    minor = np.where(hide, np.nan, f['obs_minor'].astype(float))
+    rarea = np.pi / (4. * np.log(2.)) * beam[0] * beam[1] / dx / dx
+    return dict(x=x, z=z, v=v, beam=beam, major=major, minor=minor,
+                raw_major=f['obs_major'], raw_minor=f['obs_minor'],
+                sigma=float(f['obs_sigma']), rarea=rarea)
+
+
+def make_pvfit():
+    """(MockPVD with observations attached, per-call keywords) for P5."""
+    from .mockpvd import MockPVD
+    d = _pv_example_data()
+    e = PV_EXAMPLE
+    m = MockPVD(d['x'], d['z'], d['v'], nnest=e['nnest'], beam=d['beam'],
+                reslim=e['reslim'], signmajor=e['signmajor'], signminor=e['signminor'],
+                pa_major=e['pa_major'], pa_minor=e['pa_minor'])
+    m.set_observations(d['major'], d['minor'], d['sigma'], d['rarea'])
+    return m, dict(incl=e['incl'], linewidth=e['linewidth'], rin=e['rin'],
+                   rout=float(np.max(d['z'])))
+
+
+def make_pvfit_oracle(orc, rc_first):
+    """The same fit for oracle/pvfitting_oracle.py (passed in by the caller:
+    bench.py's cpu_baseline leg or a test)."""
+    d = _pv_example_data()
+    e = PV_EXAMPLE
+    s = orc.make_setup(d['x'], d['z'], d['v'], d['beam'], incl=e['incl'],
+                       rc_first=rc_first, nnest=e['nnest'], reslim=e['reslim'],
+                       signmajor=e['signmajor'], signminor=e['signminor'],
+                       pa_major=e['pa_major'], pa_minor=e['pa_minor'],
+                       linewidth=e['linewidth'], rin=e['rin'], rout=float(np.max(d['z'])))
+    obs = orc.make_obs(d['x'], d['v'], d['raw_major'], d['raw_minor'], d['sigma'],
+                       d['beam'][0], d['beam'][1], vmask=e['vmask'])
+    return s, obs
+
+
+def pv_walkers(nw, seed=2024):
+    """Natural-unit rows (Mstar, Rc, alphainfall, taumax, frho, sig_mdl): the
+    example's free parameters uniform in its (log10) priors
+    (example_pvfitting.py:25-31), alphainfall=0.6 and sig_mdl=5 fixed."""
+    u = np.random.default_rng(seed).random((nw, 4))
+    lo = np.log10([0.1, 30., 1e-2, 1.])
+    hi = np.log10([1.0, 300., 1e4, 1e3])
+    p = 10**(lo + (hi - lo) * u)
+    Q = np.empty((nw, 6))
+    Q[:, 0], Q[:, 1], Q[:, 3], Q[:, 4] = p.T
+    Q[:, 2], Q[:, 5] = 0.6, 5.0
+    return Q
