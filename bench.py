@@ -208,12 +208,28 @@ def run_pv(args, rank, world, torch, dist):
                    'lnp_checksum': float(np.sum(lnp))},
         'roofline': {'bound': 'hbm', 'kernel': 'k_pv_tau', 'achieved': achieved / 1e9,
                      'peak': HBM_PEAK / 1e9, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK,
-                     'traffic': None, 'bytes_per_launch': alg_tau * evals_rank / cnt,
+                     'traffic': pv_traffic(eng), 'bytes_per_launch': alg_tau * evals_rank / cnt,
                      'ms_per_launch': ms / cnt, 'launches': cnt, 'per_kernel': per_kernel},
     }
     if world == 1 and args.cpu_evals > 0:
         out['cpu_baseline'] = cpu_baseline_pv(kw, Q, lnp, max(args.cpu_evals, 8))
     print(json.dumps(out), flush=True)
+
+
+def pv_traffic(eng):
+    """HBM bytes per k_pv_tau launch from the committed rocprofv3 PMC passes of
+    this same command (profiles/pv_traffic.json; FETCH_SIZE x2 + WRITE_SIZE, as
+    for the channelfit kernels), or null."""
+    try:
+        t = json.load(open(os.path.join(ROOT, 'profiles', 'pv_traffic.json')))
+    except Exception:
+        return None
+    if t.get('_meta', {}).get('walkers_per_launch') != eng.walkers_per_group:
+        return None
+    for k, v in t.items():
+        if k.startswith('k_pv_tau'):
+            return 2.0 * v['fetch_bytes_per_launch_max'] + v['write_bytes_per_launch_max']
+    return None
 
 
 def cpu_baseline_pv(kw, Q, lnp_gpu, nevals):
