@@ -16,7 +16,7 @@ from slam_amd.sharding import ShardedLikelihood, partition
 
 def fake_chi2(P):
     P = np.asarray(P)
-    return np.sum(P * np.arange(1, 14), axis=1) + np.prod(P[:, :3], axis=1)
+    return np.sum(P * np.arange(1, P.shape[1] + 1), axis=1) + np.prod(P[:, :3], axis=1)
 
 
 def _free_port():
@@ -27,12 +27,12 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, nw, out_dir):
+def _worker(rank, world, port, nw, out_dir, nparam=13):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
-        sh = ShardedLikelihood(fake_chi2, device='cpu')
-        P = np.random.default_rng(5).random((nw, 13)) if rank == 0 else None
+        sh = ShardedLikelihood(fake_chi2, device='cpu', nparam=nparam)
+        P = np.random.default_rng(5).random((nw, nparam)) if rank == 0 else None
         got = sh.chi2(P, nw).numpy()
         np.save(os.path.join(out_dir, f'r{rank}.npy'), got)
     finally:
@@ -54,6 +54,15 @@ def test_sharded_equals_single(tmp_path, world, nw):
     for r in range(world):
         got = np.load(tmp_path / f'r{r}.npy')
         assert np.array_equal(got, ref), r       # bitwise, on every rank
+
+
+def test_sharded_six_parameter_rows(tmp_path):
+    """The mock-PV likelihood's 6-parameter rows take the same route."""
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, 9, str(tmp_path), 6), nprocs=2, join=True)
+    ref = fake_chi2(np.random.default_rng(5).random((9, 6)))
+    for r in range(2):
+        assert np.array_equal(np.load(tmp_path / f'r{r}.npy'), ref), r
 
 
 def test_single_process_passthrough():
