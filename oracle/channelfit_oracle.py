@@ -25,6 +25,7 @@ from __future__ import annotations
 
 import numpy as np
 from scipy.interpolate import RegularGridInterpolator
+from scipy.optimize import curve_fit
 from scipy.signal import convolve
 from scipy.special import erf
 
@@ -60,10 +61,114 @@ def moment_signs(data_valid, v_valid, sigma, X, Y, pa_rad):
     return signmajor, signminor
 
 
+def moment0(data_valid, v_valid, sigma):
+    """(mom0, sigma_mom0) of `makemom01` (:40-44)."""
+    dvmin = np.min(v_valid[1:] - v_valid[:-1])
+    return (np.sum(data_valid, axis=0) * dvmin,
+            sigma * dvmin * np.sqrt(len(data_valid)))
+
+
+def clean_mom0(mom0, beam, sigma, threshold=2, gain=0.01, weakest=0.3):
+    """Hogbom-style CLEAN of the moment-0 map in Jy/pixel (:52-87): peak by
+    peak, a component max(gain*peak, weakest*sigma)/beamarea is moved from the
+    residual to the model until the residual peak drops under threshold*sigma;
+    the last residual (per beam area) is added back."""
+    area = np.sum(beam)
+    model = mom0 * 0
+    resid = mom0 * 1
+    for _ in range(10000000 - 1):
+        if np.nanmax(resid) < threshold * sigma:
+            break
+        at = np.unravel_index(np.nanargmax(resid), mom0.shape)
+        comp = np.zeros_like(mom0)
+        comp[at] = max(gain * resid[at], weakest * sigma) / area
+        resid = resid - convolve(comp, beam, mode='same')
+        model = model + comp
+    return model + resid / area
+
+
+def ft_deconvolve(mom0, x, y, bmaj, bmin, bpa, sigma, threshold=3):
+    """Division by the beam in the Fourier plane (:180-210): odd-sized crop,
+    beam transform made real and floored at 1 % of its peak (set to 1 below),
+    pixels under threshold*sigma zeroed, the cropped row/column put back as 0."""
+    cx, cy = int(len(x) % 2 == 0), int(len(y) % 2 == 0)
+    xd, yd, d = x[cx:], y[cy:], mom0[cy:, cx:]
+    ny, nx = d.shape
+    hy, hx = (ny - 1) // 2, (nx - 1) // 2
+    dx, dy = x[1] - x[0], y[1] - y[0]
+    xg = np.linspace(-hx * dx, hx * dx, nx)
+    yg = np.linspace(-hy * dy, hy * dy, ny)
+    s, t = rot(*np.meshgrid(xg, yg), np.radians(bpa))
+    g = np.exp2(-4 * ((t / bmaj)**2 + (s / bmin)**2))
+    u, w = np.meshgrid(np.fft.fftshift(np.fft.fftfreq(nx, d=dx)),
+                       np.fft.fftshift(np.fft.fftfreq(ny, d=dy)))
+    ph = 2 * np.pi * (u * (xg[-1] + dx) + w * (yg[-1] + dy))
+    re = np.real(np.fft.fftshift(np.fft.fft2(g)) * np.exp(-1j * ph))
+    Fg = re + 1j * 0
+    Fg[re < np.max(re) * 1e-2] = 1 + 1j * 0
+    ph = 2 * np.pi * (u * (xd[-1] + dx) + w * (yd[-1] + dy))
+    Fd = np.fft.fftshift(np.fft.fft2(d)) * np.exp(-1j * ph)
+    out = np.real(np.fft.ifft2(np.fft.ifftshift(Fd / Fg * np.exp(1j * ph))))
+    out[np.abs(d) < sigma * threshold] = 0
+    if cx:
+        out = np.concatenate((np.zeros((out.shape[0], 1)), out), axis=1)
+    if cy:
+        out = np.concatenate((np.zeros((1, out.shape[1])), out), axis=0)
+    return out
+
+
+def model_deconvolve(mom0, x, y, bmaj, bmin, bpa, sigma, niter=20):
+    """Coarse-grid deconvolution (:89-178, the default iterative branch): the
+    map is rotated into the beam frame, sampled every half beam, and each
+    sample is fitted in turn (20 sweeps) so that the bilinear model times the
+    beam centred on it reproduces the rotated map there; samples under 2 sigma
+    are zeroed.  Returns the model interpolated back onto (y, x)."""
+    nx, ny = len(x), len(y)
+    dx, dy = np.abs(x[1] - x[0]), np.abs(y[1] - y[0])
+    sx, sy = int(np.floor(bmin / 2 / dx)), int(np.floor(bmaj / 2 / dy))
+    hx = int(np.floor((nx - 1) / 2 / sx)) * sx
+    hy = int(np.floor((ny - 1) / 2 / sy)) * sy
+    mx, my = 2 * hx + 1, 2 * hy + 1
+    ox, oy = int((nx - mx) / 2), int((ny - my) / 2)
+    xi = x[::-1][ox:mx + ox]
+    yi = y[oy:my + oy]
+    di = mom0[:, ::-1][oy:my + oy, ox:mx + ox]
+    Xi, Yi = np.meshgrid(xi, yi)
+    g = np.exp2(-((Xi - xi[hx]) / (bmin / 2))**2 - ((Yi - yi[hy]) / (bmaj / 2))**2)
+    gsum = np.sum(g)
+    xm, ym = xi[::sx], yi[::sy]
+    lin = dict(method='linear', bounds_error=False, fill_value=0)
+    drot = RegularGridInterpolator((yi, xi), di, **lin)(
+        tuple(rot(Xi, Yi, -np.radians(bpa)))[::-1])
+    par = drot[::sy, ::sx].clip(0, None) / gsum
+    for _ in range(niter):
+        for ip in range(len(ym)):
+            for jp in range(len(xm)):
+                target = drot[ip * sy, jp * sx]
+                if target < 2 * sigma:
+                    par[ip, jp] = 0
+                    continue
+                shifted = np.roll(g, (ip * sy - hy, jp * sx - hx), axis=(0, 1))
+
+                def response(pts, value):
+                    trial = par + 0
+                    trial[ip, jp] = value
+                    f = RegularGridInterpolator((ym, xm), trial, **lin)
+                    return np.sum(f(tuple(pts)) * shifted)
+                best, _ = curve_fit(response, [Yi, Xi], target, p0=par[ip, jp],
+                                    sigma=[sigma], absolute_sigma=True,
+                                    bounds=[0, target])
+                par[ip, jp] = best[0]
+    f = RegularGridInterpolator((ym, xm), np.reshape(np.ravel(par), (len(ym), len(xm))),
+                                **lin)
+    return f(tuple(rot(*np.meshgrid(x, y), np.radians(bpa)))[::-1])
+
+
 def make_setup(x, y, v, data, *, bmaj, bmin, bpa, sigma, pa, incl, rmax,
                vlim=(-100, 0, 0, 100), nlayer=3, gaussmargin=1.6,
-               signmajor=None, signminor=None, disk=True, envelope=False):
-    """Everything `makegrid` (:227-341) derives once per fit, as a dict."""
+               signmajor=None, signminor=None, disk=True, envelope=False,
+               scaling='uniform'):
+    """Everything `makegrid` (:227-371) derives once per fit, as a dict."""
     x, y, v = (np.asarray(a, dtype=float) for a in (x, y, v))
     dx, dy, dv = x[1] - x[0], y[1] - y[0], v[1] - v[0]      # utils.py:260-262
     dpix = min(abs(dx), abs(dy))                             # :243
@@ -99,7 +204,18 @@ def make_setup(x, y, v, data, *, bmaj, bmin, bpa, sigma, pa, incl, rmax,
     n_need = int(r_need / dpix + 0.5)
     ineed0, ineed1 = npix // 2 - n_need, npix // 2 + n_need
     xneed = axes[0][ineed0:ineed1]
-    return dict(x=x, y=y, X=X, Y=Y, dv=dv, dpix=dpix, sigma=float(sigma),
+    mom0decon = None
+    if 'mom0' in scaling:                                    # :343-364
+        gaussbeam = gaussbeam[:, ::-1]       # x axis into the observed order
+        mom0, sig0 = moment0(data_valid, v_valid, sigma)
+        if scaling == 'mom0clean':
+            mom0decon = clean_mom0(mom0, gaussbeam, sig0)
+        elif scaling == 'mom0model':
+            mom0decon = model_deconvolve(mom0, x, y, bmaj, bmin, bpa, sig0)
+        elif scaling == 'mom0ft':
+            mom0decon = ft_deconvolve(mom0, x, y, bmaj, bmin, bpa, sig0)
+    return dict(scaling=scaling, mom0decon=mom0decon,
+                x=x, y=y, X=X, Y=Y, dv=dv, dpix=dpix, sigma=float(sigma),
                 v_valid=v_valid, data_valid=data_valid,
                 signmajor=float(signmajor), signminor=float(signminor),
                 incl0=float(incl), pa_rad=pa_rad, nlayer=nlayer, npix=npix,
@@ -243,8 +359,10 @@ def scale_factor(setup, cube):
 
 
 def cubemodel(setup, p, convolving=True, stages=None):
-    """`ChannelFit.cubemodel` for scaling='uniform' with every parameter group
-    recomputed (:499-537).  `p` = 13 values in PARAMKEYS order (natural units).
+    """`ChannelFit.cubemodel` with every parameter group recomputed (:499-537);
+    `setup['scaling']` selects 'uniform' or one of the 'mom0*' variants (then
+    stages 'Iregrid' = regridded unconvolved cube, 'Iconv' = the same after
+    the per-pixel moment-0 scale).  `p` = 13 values in PARAMKEYS order (natural units).
     If `stages` is a dict it receives the intermediate arrays.
     """
     (Mstar, Rc, cs, h1, h2, pI, Rin, Ienv,
@@ -266,10 +384,18 @@ def cubemodel(setup, p, convolving=True, stages=None):
         else:
             Iu = iunif(setup, xs, vl, Ynest, prof, prof_n, prof_d,
                        Mstar, Rc, pI, Ienv, voff)
-        Ic = beam_convolve(setup, Iu) if convolving else peaktounity(Iu)
-        Ir = regrid(setup, xoff, yoff, Ic)
-        s, gf, ff = scale_factor(setup, Ir)
-        out = Ir * s
+        if 'mom0' in setup.get('scaling', 'uniform'):              # :520-532
+            Io = regrid(setup, xoff, yoff, Iu)
+            m0 = np.sum(Io, axis=0) * setup['dv']
+            m0[m0 < 0] = np.nan
+            Is = np.nan_to_num(Io * setup['mom0decon'] / m0)
+            out = beam_convolve(setup, Is) if convolving else peaktounity(Is)
+            Ic, Ir, s, gf, ff = Is, Io, np.nan, np.nan, np.nan
+        else:
+            Ic = beam_convolve(setup, Iu) if convolving else peaktounity(Iu)
+            Ir = regrid(setup, xoff, yoff, Ic)
+            s, gf, ff = scale_factor(setup, Ir)
+            out = Ir * s
     if stages is not None:
         stages.update(prof=prof, prof_d=prof_d, xdisk=xs, vlos=vl, Iunif=Iu,
                       Iconv=Ic, Iregrid=Ir, scale=s, gf=gf, ff=ff)
