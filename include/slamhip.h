@@ -69,6 +69,12 @@ typedef struct slamhip_desc {
   const double* data_valid; /* [nv][ny][nx]                         :274 */
   const double* gaussbeam;  /* [kbeam][kbeam], not normalised       :333 */
   int64_t max_scratch_bytes; /* cap on per-batch device scratch; 0 = default */
+  const double* mom0decon;  /* [ny][nx] deconvolved moment 0 for the 'mom0*'
+                             * scalings (:343-364), NULL = scaling 'uniform'.
+                             * With it, `gaussbeam` is the x-flipped kernel of
+                             * :345, the model is regrid -> per-pixel moment-0
+                             * scale -> beam on the observed grid (:520-530)
+                             * and has no global amplitude (:533-536).        */
 } slamhip_desc;
 
 typedef struct slamhip_ctx slamhip_ctx;

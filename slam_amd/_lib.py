@@ -34,6 +34,7 @@ class SlamhipDesc(C.Structure):
         ('xobs', _dp), ('yobs', _dp), ('v_valid', _dp), ('data_valid', _dp),
         ('gaussbeam', _dp),
         ('max_scratch_bytes', C.c_int64),
+        ('mom0decon', _dp),
     ]
 
 

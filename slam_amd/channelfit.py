@@ -11,9 +11,11 @@ signatures and result attributes (`popt/plow/pmid/phigh` dicts, `chi2r`,
   half-ensemble instead of one Python `cubemodel` call per walker (:594-603).
 * `cubemodel` is one C-ABI call (:499-537).
 
-Only `scaling='uniform'` is implemented on the GPU (SURVEY.md section 8f lists
-the `mom0*` variants as next); anything else raises NotImplementedError rather
-than silently taking another path.
+`scaling` is 'uniform' (least-squares amplitude, :533-536) or one of 'mom0ft',
+'mom0clean', 'mom0model' (per-pixel moment-0 scaling, :343-371, :520-525): the
+deconvolved moment-0 map is made on the host in `makegrid` (slam_amd/deconv.py)
+and the reordered forward model runs on the GPU.  Anything else raises
+ValueError rather than silently taking another path.
 """
 from __future__ import annotations
 
@@ -33,6 +35,9 @@ _UNITS = ['Msun', 'au', 'km/s', '', '', '', 'au', '', 'au', 'au', 'km/s',
           'deg', 'deg']
 _DIGITS = [2, 0, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2]
 _ILOG = np.array([0, 1, 7])          # Mstar, Rc, Ienv are sampled in log10 (:578)
+
+
+SCALINGS = ('uniform', 'mom0ft', 'mom0clean', 'mom0model')
 
 
 def makemom01(d, v, sigma):
@@ -59,9 +64,8 @@ class ChannelFit(ReadFits):
         self.progressbar = progressbar
         self._engine = None
         self._max_scratch_bytes = 0
-        if scaling != 'uniform':
-            raise NotImplementedError(
-                f"scaling='{scaling}': only 'uniform' runs on the GPU path")
+        if scaling not in SCALINGS:
+            raise ValueError(f"scaling='{scaling}': expected one of {SCALINGS}")
 
     # -- synthetic / in-memory input (extension; the reference reads FITS only)
     def set_cube(self, x, y, v, data, bmaj, bmin, bpa, sigma):
@@ -177,6 +181,39 @@ class ChannelFit(ReadFits):
         self.xneed = self.xnest[0][self.ineed0:self.ineed1]
         self.yneed = self.ynest[0][self.ineed0:self.ineed1]
 
+        # per-pixel moment-0 scaling (:343-371): x axis of the beam into the
+        # observed order, deconvolved moment-0 map by the chosen method
+        self.mom0decon = None
+        if 'mom0' in self.scaling:
+            from . import deconv
+            self.gaussbeam = self.gaussbeam[:, ::-1]
+            if self.scaling == 'mom0clean':
+                self.mom0decon = deconv.clean(
+                    data=self.mom0, beam=self.gaussbeam, sigma=self.sigma_mom0,
+                    savetxt=savedeconvolved, loadtxt=loaddeconvolved,
+                    verbose=self.progressbar)
+            elif self.scaling == 'mom0model':
+                d = deconv.modeldeconvolve(
+                    x=self.x, y=self.y, data=self.mom0, bmaj=self.bmaj,
+                    bmin=self.bmin, bpa=self.bpa, sigma=self.sigma_mom0,
+                    savetxt=savedeconvolved, loadtxt=loaddeconvolved,
+                    progressbar=self.progressbar)
+                self.mom0decon, self.xdecon, self.ydecon, self.zdecon = d
+                print('Found a deconvolved solution.')
+            else:
+                self.mom0decon = deconv.ftdeconvolve(
+                    x=self.x, y=self.y, data=self.mom0, bmaj=self.bmaj,
+                    bmin=self.bmin, bpa=self.bpa, sigma=self.sigma_mom0,
+                    threshold=3)
+                print('Divided in the Fourier space.')
+            from scipy.signal import convolve
+            self.resdecon = self.mom0 - convolve(self.mom0decon, self.gaussbeam,
+                                                 mode='same')
+            maxres = np.max(self.resdecon) / self.sigma_mom0
+            rmsres = np.sqrt(np.mean(self.resdecon**2)) / self.sigma_mom0
+            print(f'Max and rms are {maxres:.1f}sigma '
+                  + f'and {rmsres:.1f}sigma in Moment 0 residual.')
+
         # the constants go to the GPU on first use of the likelihood
         self.close()
         self._max_scratch_bytes = max_scratch_bytes
@@ -210,6 +247,7 @@ class ChannelFit(ReadFits):
                 'y', 'v_valid', 'data_valid', 'gaussbeam')
         d = {k: getattr(self, k) for k in keys}
         d['vunit'] = vunit
+        d['mom0decon'] = getattr(self, 'mom0decon', None)
         return d
 
     # -- forward model -------------------------------------------------------

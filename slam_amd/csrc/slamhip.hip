@@ -67,6 +67,7 @@ struct FitK {
   const double* ch_vmax;
   const double* data;       // [nv][ny][nx]
   const double* beam;       // [K][K]
+  const double* mom0decon;  // [ny][nx] deconvolved moment 0, or null (scaling='uniform')
   const double* gx_pad;     // separable factors, flipped + zero padded
   const double* gy_pad;
   const unsigned* leaf;     // [nslot] packed (layer:4 | row:14 | col:14), LEAF_PAD = none
@@ -1121,9 +1122,9 @@ k_conv_2d(FitK g, const double* __restrict__ in, double* __restrict__ out) {
 
 // peaktounity (:492-497): per-channel max, then scale by 1/max (0 if max == 0).
 __global__ void __launch_bounds__(256)
-k_peak_unity(FitK g, const double* __restrict__ in, double* __restrict__ out) {
+k_peak_unity(FitK g, const double* __restrict__ in, double* __restrict__ out,
+             long long plane) {
   __shared__ double red[256];
-  const long long plane = (long long)g.nneed * g.nneed;
   const double* src = in + (long long)blockIdx.x * plane;
   double* dst = out + (long long)blockIdx.x * plane;
   double m = -std::numeric_limits<double>::infinity();
@@ -1177,7 +1178,7 @@ k_regrid(FitK g, const int* __restrict__ cellx, const double* __restrict__ fracx
             v10 * t0 * (1 - t1) + v11 * t0 * t1;
     }
     const long long e = obase + (long long)jy * g.nx + ix;
-    if (WRITE) cube_out[e] = val;
+    if (WRITE) cube_out[(long long)wi * g.nv * g.ny * g.nx + e] = val;
     gf = fma(val, g.data[e], gf);
     ff = fma(val, val, ff);
   }
@@ -1243,6 +1244,123 @@ k_finalize(FitK g, const double* __restrict__ partial, int nblk,
   }
 }
 
+
+// ---------------------------------------------------------------------------
+// 'mom0*' scalings (:520-532): the UNCONVOLVED cube is regridded first, every
+// pixel's spectrum is rescaled so that its moment 0 equals the deconvolved
+// observed one, and the beam is applied on the observed grid.
+// ---------------------------------------------------------------------------
+// k_mom0_scale: cube[w][k][p] <- nan_to_num(cube * mom0decon[p] / (sum_k cube * dv)),
+// a negative moment 0 counting as NaN (:522-525).  Thread per (walker, pixel).
+__global__ void __launch_bounds__(256)
+k_mom0_scale(FitK g, double* __restrict__ cube) {
+  const long long npix = (long long)g.ny * g.nx;
+  const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (p >= npix) return;
+  double* c = cube + (long long)blockIdx.y * g.nv * npix + p;
+  double m0 = 0.0;
+  for (int k = 0; k < g.nv; ++k) m0 += c[(long long)k * npix];
+  m0 = m0 * g.dv;
+  if (m0 < 0.0) m0 = __builtin_nan("");
+  const double dec = g.mom0decon[p];
+  const double big = std::numeric_limits<double>::max();
+  for (int k = 0; k < g.nv; ++k) {
+    double v = c[(long long)k * npix] * dec / m0;
+    if (v != v) v = 0.0;
+    else if (v > big) v = big;
+    else if (v < -big) v = -big;
+    c[(long long)k * npix] = v;
+  }
+}
+
+// k_conv_obs: zero-padded 'same' convolution with the K x K beam on the observed
+// (ny, nx) grid (:530), direct taps on an LDS tile, fused with the residual sum
+// of lnprob (:601): partial[block] = sum over its pixels of (data - model)^2,
+// NaN terms skipped like nansum.  WRITE also stores the model cube.
+template <bool WRITE>
+__global__ void __launch_bounds__(256)
+k_conv_obs(FitK g, const double* __restrict__ in, double* __restrict__ out,
+           double* __restrict__ partial) {
+  extern __shared__ double lds[];
+  const int K = g.kbeam, ng = g.ngauss, nx = g.nx, ny = g.ny;
+  const int rows = C2_TY + K - 1, cols = C2_TX + K - 1;
+  const int P = cols | 1;
+  const int tid = threadIdx.x;
+  const long long plane = (long long)ny * nx;
+  const int k = blockIdx.z % g.nv;
+  const double* src = in + (long long)blockIdx.z * plane;
+  const int x0 = blockIdx.x * C2_TX, y0 = blockIdx.y * C2_TY;
+  for (int e = tid; e < rows * P; e += 256) {
+    const int rr = e / P, cc = e - rr * P;
+    const int gy = y0 - ng + rr, gx = x0 - ng + cc;
+    double v = 0.0;
+    if (cc < cols && gy >= 0 && gy < ny && gx >= 0 && gx < nx)
+      v = src[(long long)gy * nx + gx];
+    lds[e] = v;
+  }
+  __syncthreads();
+  const int tx = tid & 63, ty = tid >> 6;
+  double acc[C2_RY];
+#pragma unroll
+  for (int r = 0; r < C2_RY; ++r) acc[r] = 0.0;
+  for (int a = 0; a < K; ++a) {
+    const double* brow = g.beam + (long long)(K - 1 - a) * K;
+    for (int b = 0; b < K; ++b) {
+      const double wgt = brow[K - 1 - b];
+#pragma unroll
+      for (int r = 0; r < C2_RY; ++r)
+        acc[r] = fma(wgt, lds[(ty + 4 * r + a) * P + tx + b], acc[r]);
+    }
+  }
+  const int gx = x0 + tx;
+  double ss = 0.0;
+#pragma unroll
+  for (int r = 0; r < C2_RY; ++r) {
+    const int gy = y0 + ty + 4 * r;
+    if (gx < nx && gy < ny) {
+      const long long e = (long long)gy * nx + gx;
+      if (WRITE) out[(long long)blockIdx.z * plane + e] = acc[r];
+      const double d = g.data[(long long)k * plane + e] - acc[r];
+      const double q = d * d;
+      if (q == q) ss += q;
+    }
+  }
+  __shared__ double sred[4];
+  ss = wave_sum(ss);
+  if ((tid & 63) == 0) sred[tid >> 6] = ss;
+  __syncthreads();
+  if (tid == 0) {
+    const long long blk = ((long long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    partial[blk] = (sred[0] + sred[1]) + (sred[2] + sred[3]);
+  }
+}
+
+// k_sum_chi2: one block per walker, fixed-order sum of its residual partials,
+// chi2 = sum / sigma^2 / pixperbeam (:601-602).  stats = {nan, nan, nan, chi2, 0, nblk}
+// (the mom0 scalings have no global amplitude).
+__global__ void __launch_bounds__(256)
+k_sum_chi2(FitK g, const double* __restrict__ partial, int nblk,
+           double* __restrict__ stats, double* __restrict__ chi2_out) {
+  __shared__ double sa[4];
+  const int wi = blockIdx.x;
+  const double* p = partial + (long long)wi * nblk;
+  double a = 0.0;
+  for (int q = threadIdx.x; q < nblk; q += 256) a += p[q];
+  a = wave_sum(a);
+  if ((threadIdx.x & 63) == 0) sa[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    a = (sa[0] + sa[1]) + (sa[2] + sa[3]);
+    const double c2 = a / (g.sigma * g.sigma) / g.pixperbeam;
+    if (stats) {
+      const double nn = __builtin_nan("");
+      stats[6 * wi + 0] = nn; stats[6 * wi + 1] = nn; stats[6 * wi + 2] = nn;
+      stats[6 * wi + 3] = c2; stats[6 * wi + 4] = 0.0; stats[6 * wi + 5] = (double)nblk;
+    }
+    if (chi2_out) chi2_out[wi] = c2;
+  }
+}
+
 __global__ void k_scale(double* __restrict__ cube, long long n,
                         const double* __restrict__ stats) {
   const double s = stats[2];
@@ -1268,6 +1386,9 @@ struct slamhip_ctx {
   double2* d_geom = nullptr;   // [walker][surface][sample] {vlos*sqrt(M), weight}
   double* d_iunif = nullptr;
   double* d_iconv = nullptr;
+  double* d_obs = nullptr;     // 'mom0*' scalings: [walker][nv][ny][nx] regridded cube
+  dim3 ob_grid{1, 1, 1};       // k_conv_obs grid for ONE walker (z = nv)
+  int ob_blocks = 0;
   double* d_partial = nullptr;
   double* d_stats = nullptr;
   double* d_chi2 = nullptr;
@@ -1522,8 +1643,53 @@ int run_model(slamhip_ctx* c, const double* d_params, int nw, hipStream_t st, bo
   return SLAMHIP_OK;
 }
 
+// 'mom0*' scalings: Iunif -> observed grid -> per-pixel moment-0 scale -> beam on
+// the observed grid -> residual sum.  `d_model` (may be null) receives the
+// model cubes [nw][nv][ny][nx].
+int run_group_mom0(slamhip_ctx* c, const double* d_params, int nw, double* d_chi2,
+                   double* d_model, bool convolving, hipStream_t st) {
+  const FitK& k = c->k;
+  int rc = run_model(c, d_params, nw, st, true);
+  if (rc) return rc;
+  {
+    Timed t_(c, KID_REGRID, st);
+    dim3 g4(c->rg_grid.x, c->rg_grid.y, c->rg_grid.z * nw);
+    hipLaunchKernelGGL((k_regrid<true>), g4, dim3(RED_THREADS), 0, st, k, c->d_cellx,
+                       c->d_fracx, c->d_celly, c->d_fracy, c->d_iunif, c->d_partial, c->d_obs);
+    const long long npix = (long long)k.ny * k.nx;
+    hipLaunchKernelGGL(k_mom0_scale, dim3((unsigned)((npix + 255) / 256), nw), dim3(256), 0, st, k,
+                       c->d_obs);
+  }
+  if (!convolving) {       // peaktounity on the observed grid (:531-532), single-vector product
+    hipLaunchKernelGGL(k_peak_unity, dim3(k.nv * nw), dim3(256), 0, st, k, c->d_obs, d_model,
+                       (long long)k.ny * k.nx);
+    HIP_TRY(c, hipGetLastError());
+    return SLAMHIP_OK;
+  }
+  if (c->c2d_lds > 160 * 1024)
+    return fail(c, SLAMHIP_ERR_ARG, "beam kernel %d too large for the 2-D LDS tile", k.kbeam);
+  {
+    Timed t_(c, KID_CONV, st);
+    dim3 g(c->ob_grid.x, c->ob_grid.y, c->ob_grid.z * nw);
+    if (d_model)
+      hipLaunchKernelGGL((k_conv_obs<true>), g, dim3(256), c->c2d_lds, st, k, c->d_obs, d_model,
+                         c->d_partial);
+    else
+      hipLaunchKernelGGL((k_conv_obs<false>), g, dim3(256), c->c2d_lds, st, k, c->d_obs,
+                         (double*)nullptr, c->d_partial);
+  }
+  {
+    Timed t_(c, KID_FINALIZE, st);
+    hipLaunchKernelGGL(k_sum_chi2, dim3(nw), dim3(256), 0, st, k, c->d_partial, c->ob_blocks,
+                       c->d_stats, d_chi2);
+  }
+  HIP_TRY(c, hipGetLastError());
+  return SLAMHIP_OK;
+}
+
 int run_group(slamhip_ctx* c, const double* d_params, int nw, double* d_chi2,
               hipStream_t st) {
+  if (c->k.mom0decon) return run_group_mom0(c, d_params, nw, d_chi2, nullptr, true, st);
   const bool fused = c->fused && c->conv_mode == 0;
   int rc = run_model(c, d_params, nw, st, !fused);
   if (rc) return rc;
@@ -1749,9 +1915,14 @@ int slamhip_create(const slamhip_desc* d, slamhip_ctx** out) {
     c->fz_sy = ty - 1;
     c->fz_grid = dim3((n - 1 + c->fz_sx - 1) / c->fz_sx, (n - 1 + c->fz_sy - 1) / c->fz_sy, k.nv);
   }
-  if (c->c2d_lds > 48 * 1024 && c->c2d_lds <= 160 * 1024)
+  if (c->c2d_lds > 48 * 1024 && c->c2d_lds <= 160 * 1024) {
     HIP_TRY(c, hipFuncSetAttribute((const void*)k_conv_2d,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->c2d_lds));
+    HIP_TRY(c, hipFuncSetAttribute((const void*)k_conv_obs<true>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->c2d_lds));
+    HIP_TRY(c, hipFuncSetAttribute((const void*)k_conv_obs<false>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->c2d_lds));
+  }
 
   // --- uploads -------------------------------------------------------------
   int rc;
@@ -1766,6 +1937,8 @@ int slamhip_create(const slamhip_desc* d, slamhip_ctx** out) {
   if ((rc = dev_upload(c, &k.ch_vmax, cmax.data(), cmax.size()))) return rc;
   if ((rc = dev_upload(c, &k.data, d->data_valid, ncube))) return rc;
   if ((rc = dev_upload(c, &k.beam, d->gaussbeam, (size_t)K * K))) return rc;
+  k.mom0decon = nullptr;
+  if (d->mom0decon && (rc = dev_upload(c, &k.mom0decon, d->mom0decon, (size_t)k.ny * k.nx))) return rc;
   if ((rc = dev_upload(c, &k.gx_pad, gx.data(), gx.size()))) return rc;
   if ((rc = dev_upload(c, &k.gy_pad, gy.data(), gy.size()))) return rc;
   if ((rc = dev_upload(c, &k.leaf, leaves.data(), leaves.size()))) return rc;
@@ -1773,7 +1946,8 @@ int slamhip_create(const slamhip_desc* d, slamhip_ctx** out) {
   if ((rc = dev_upload(c, &k.tile_nl, tile_nl.data(), tile_nl.size()))) return rc;
 
   // --- per-group scratch -----------------------------------------------------
-  const size_t per_walker = sizeof(double) * (8 * (size_t)k.nslot + 2 * (size_t)k.nv * n * n);
+  const size_t per_walker = sizeof(double) * (8 * (size_t)k.nslot + 2 * (size_t)k.nv * n * n +
+                                              (d->mom0decon ? ncube : 0));
   size_t freeb = 0, totalb = 0;
   HIP_TRY(c, hipMemGetInfo(&freeb, &totalb));
   size_t budget = d->max_scratch_bytes > 0 ? (size_t)d->max_scratch_bytes : ((size_t)24 << 30);
@@ -1783,13 +1957,17 @@ int slamhip_create(const slamhip_desc* d, slamhip_ctx** out) {
   while (c->wgroup > 1 && (long long)c->wgroup * k.nv > 32768) --c->wgroup;
   c->rg_grid = dim3((k.nx + RED_THREADS - 1) / RED_THREADS, (k.ny + RG_ROWS - 1) / RG_ROWS, k.nv);
   c->red_blocks = (int)(c->rg_grid.x * c->rg_grid.y * c->rg_grid.z);
-  const size_t max_blocks = std::max<size_t>(c->red_blocks, (size_t)c->fz_grid.x * c->fz_grid.y * c->fz_grid.z);
+  c->ob_grid = dim3((k.nx + C2_TX - 1) / C2_TX, (k.ny + C2_TY - 1) / C2_TY, k.nv);
+  c->ob_blocks = (int)(c->ob_grid.x * c->ob_grid.y * c->ob_grid.z);
+  const size_t max_blocks = std::max<size_t>(std::max<size_t>(c->red_blocks, c->ob_blocks),
+                                             (size_t)c->fz_grid.x * c->fz_grid.y * c->fz_grid.z);
   const size_t W = c->wgroup;
   if ((rc = dev_alloc(c, &c->d_wk, W))) return rc;
   if ((rc = dev_alloc(c, &c->d_params, W * NP))) return rc;
   if ((rc = dev_alloc(c, &c->d_geom, W * 4 * k.nslot))) return rc;
   if ((rc = dev_alloc(c, &c->d_iunif, W * k.nv * n * n))) return rc;
   if ((rc = dev_alloc(c, &c->d_iconv, W * k.nv * n * n))) return rc;
+  if (d->mom0decon && (rc = dev_alloc(c, &c->d_obs, W * ncube))) return rc;
   if ((rc = dev_alloc(c, &c->d_partial, W * max_blocks * 3))) return rc;
   if ((rc = dev_alloc(c, &c->d_stats, W * 6))) return rc;
   if ((rc = dev_alloc(c, &c->d_chi2, W))) return rc;
@@ -1974,11 +2152,33 @@ int slamhip_cubemodel(slamhip_ctx* c, const double* params, int convolving,
   if (rc) return rc;
   if (!out) return fail(c, SLAMHIP_ERR_ARG, "null output");
   const FitK& k = c->k;
+  if (k.mom0decon) {
+    const size_t ncube = (size_t)k.nv * k.ny * k.nx;
+    double* d_cube = nullptr;
+    HIP_TRY(c, hipMalloc((void**)&d_cube, ncube * sizeof(double)));
+    rc = run_group_mom0(c, c->d_params, 1, c->d_chi2, d_cube, convolving != 0, c->stream);
+    hipError_t e = hipSuccess;
+    if (rc == SLAMHIP_OK)
+      e = hipMemcpyAsync(out, d_cube, ncube * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+    if (rc == SLAMHIP_OK && e == hipSuccess && stats_out) {
+      if (convolving) {
+        e = hipMemcpyAsync(stats_out, c->d_stats, 4 * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+      } else {
+        for (int i = 0; i < 4; ++i) stats_out[i] = std::numeric_limits<double>::quiet_NaN();
+      }
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d_cube);
+    if (rc) return rc;
+    if (e != hipSuccess) return fail(c, SLAMHIP_ERR_HIP, "cubemodel: %s", hipGetErrorString(e));
+    return SLAMHIP_OK;
+  }
   if ((rc = run_model(c, c->d_params, 1, c->stream, true))) return rc;
   if (convolving) {
     if ((rc = run_conv(c, c->d_iunif, c->d_iconv, k.nv, c->stream))) return rc;
   } else {
-    hipLaunchKernelGGL(k_peak_unity, dim3(k.nv), dim3(256), 0, c->stream, k, c->d_iunif, c->d_iconv);
+    hipLaunchKernelGGL(k_peak_unity, dim3(k.nv), dim3(256), 0, c->stream, k, c->d_iunif, c->d_iconv,
+                       (long long)k.nneed * k.nneed);
   }
   const size_t ncube = (size_t)k.nv * k.ny * k.nx;
   double* d_cube = nullptr;

@@ -24,7 +24,8 @@ class HipLikelihood:
     `slam_amd.channelfit.ChannelFit.setup_dict`): nlayer, npix, nq1, nq3,
     ineed0, ineed1, dv, sigma, pixperbeam, incl0, signmajor, signminor, vunit,
     disk, envelope, Xnest0, Ynest0, xneed, yneed, x, y, v_valid, data_valid,
-    gaussbeam.
+    gaussbeam, and optionally mom0decon (the 'mom0*' scalings; gaussbeam is then
+    the x-flipped kernel).
     """
 
     def __init__(self, setup, max_scratch_bytes=0):
@@ -51,6 +52,11 @@ class HipLikelihood:
         K = keep['gaussbeam'].shape[0]
         if keep['gaussbeam'].shape != (K, K):
             raise ValueError('gaussbeam must be square')
+        self.mom0 = s.get('mom0decon') is not None
+        if self.mom0:
+            keep['mom0decon'] = f64(s['mom0decon'])
+            if keep['mom0decon'].shape != (ny, nx):
+                raise ValueError('mom0decon must be (ny, nx)')
         d = _lib.SlamhipDesc(
             nv=nv, ny=ny, nx=nx, nlayer=nlayer, npix=npix,
             nq1=int(s['nq1']), nq3=int(s['nq3']), ineed0=int(s['ineed0']),
@@ -65,6 +71,8 @@ class HipLikelihood:
             v_valid=as_dp(keep['v_valid']), data_valid=as_dp(keep['data_valid']),
             gaussbeam=as_dp(keep['gaussbeam']),
             max_scratch_bytes=int(max_scratch_bytes))
+        if self.mom0:
+            d.mom0decon = as_dp(keep['mom0decon'])
         rc = self._lib.slamhip_create(C.byref(d), C.byref(self._ctx))
         if rc != 0:
             msg = self._errmsg()
