@@ -1335,6 +1335,86 @@ k_conv_obs(FitK g, const double* __restrict__ in, double* __restrict__ out,
   }
 }
 
+
+// k_conv_obs_sep: the same convolution + residual sum with the beam written as a
+// sum of `nrank` outer products (exactly one for an axis-aligned Gaussian; the
+// leading singular triplets, tail < 1e-13, for a rotated one): per term a row
+// pass into an LDS intermediate and a column pass, 2K instead of K^2 taps.
+template <int TY, bool WRITE>
+__global__ void __launch_bounds__(256)
+k_conv_obs_sep(FitK g, const double* __restrict__ in, double* __restrict__ out,
+               double* __restrict__ partial, int kpad, int nrank) {
+  extern __shared__ double lds[];
+  constexpr int TX = C2_TX, RY = TY / 4;
+  const int K = g.kbeam, ng = g.ngauss, nx = g.nx, ny = g.ny;
+  const int rows = TY + K - 1, cols = TX + K - 1;
+  const int P = cols | 1, P2 = TX + 1;
+  double* tile = lds;                   // [rows][P]
+  double* tmp = lds + rows * P;         // [rows][P2]
+  const int tid = threadIdx.x;
+  const long long plane = (long long)ny * nx;
+  const int k = blockIdx.z % g.nv;
+  const double* src = in + (long long)blockIdx.z * plane;
+  const int x0 = blockIdx.x * TX, y0 = blockIdx.y * TY;
+  bool any = false;
+  for (int e = tid; e < rows * P; e += 256) {
+    const int rr = e / P, cc = e - rr * P;
+    const int gy = y0 - ng + rr, gx = x0 - ng + cc;
+    double v = 0.0;
+    if (cc < cols && gy >= 0 && gy < ny && gx >= 0 && gx < nx)
+      v = src[(long long)gy * nx + gx];
+    any |= v != 0.0;
+    tile[e] = v;
+  }
+  const bool live = __syncthreads_or(any) != 0;   // empty sky convolves to zero
+  const int tx = tid & 63, ty = tid >> 6;
+  double acc[RY];
+#pragma unroll
+  for (int r = 0; r < RY; ++r) acc[r] = 0.0;
+  if (live) {
+    for (int rk = 0; rk < nrank; ++rk) {
+      const double* wx = g.gx_pad + (long long)rk * kpad;
+      const double* wy = g.gy_pad + (long long)rk * kpad;
+      if (rk) __syncthreads();
+      for (int e = tid; e < rows * TX; e += 256) {
+        const int rr = e >> 6, xx = e & 63;
+        const double* row = tile + rr * P + xx;
+        double s = 0.0;
+        for (int u = 0; u < K; ++u) s = fma(wx[u], row[u], s);
+        tmp[rr * P2 + xx] = s;
+      }
+      __syncthreads();
+      for (int u = 0; u < K; ++u) {
+        const double w = wy[u];
+#pragma unroll
+        for (int r = 0; r < RY; ++r)
+          acc[r] = fma(w, tmp[(ty + 4 * r + u) * P2 + tx], acc[r]);
+      }
+    }
+  }
+  const int gx = x0 + tx;
+  double ss = 0.0;
+#pragma unroll
+  for (int r = 0; r < RY; ++r) {
+    const int gy = y0 + ty + 4 * r;
+    if (gx < nx && gy < ny) {
+      const long long e = (long long)gy * nx + gx;
+      if (WRITE) out[(long long)blockIdx.z * plane + e] = acc[r];
+      const double d = g.data[(long long)k * plane + e] - acc[r];
+      const double q = d * d;
+      if (q == q) ss += q;
+    }
+  }
+  __shared__ double sred[4];
+  ss = wave_sum(ss);
+  if ((tid & 63) == 0) sred[tid >> 6] = ss;
+  __syncthreads();
+  if (tid == 0) {
+    const long long blk = ((long long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    partial[blk] = (sred[0] + sred[1]) + (sred[2] + sred[3]);
+  }
+}
+
 // k_sum_chi2: one block per walker, fixed-order sum of its residual partials,
 // chi2 = sum / sigma^2 / pixperbeam (:601-602).  stats = {nan, nan, nan, chi2, 0, nblk}
 // (the mom0 scalings have no global amplitude).
@@ -1389,6 +1469,8 @@ struct slamhip_ctx {
   double* d_obs = nullptr;     // 'mom0*' scalings: [walker][nv][ny][nx] regridded cube
   dim3 ob_grid{1, 1, 1};       // k_conv_obs grid for ONE walker (z = nv)
   int ob_blocks = 0;
+  int ob_ty = 0;               // rows per k_conv_obs_sep tile (32 / 16), 0 = direct taps
+  size_t ob_lds = 0;
   double* d_partial = nullptr;
   double* d_stats = nullptr;
   double* d_chi2 = nullptr;
@@ -1663,6 +1745,22 @@ int run_group_mom0(slamhip_ctx* c, const double* d_params, int nw, double* d_chi
   if (!convolving) {       // peaktounity on the observed grid (:531-532), single-vector product
     hipLaunchKernelGGL(k_peak_unity, dim3(k.nv * nw), dim3(256), 0, st, k, c->d_obs, d_model,
                        (long long)k.ny * k.nx);
+    HIP_TRY(c, hipGetLastError());
+    return SLAMHIP_OK;
+  }
+  if (c->ob_ty && c->conv_mode == 0) {
+    Timed t_(c, KID_CONV, st);
+    dim3 g(c->ob_grid.x, (k.ny + c->ob_ty - 1) / c->ob_ty, c->ob_grid.z * nw);
+#define SLAM_OBS(TY_, WR_)                                                                  \
+    hipLaunchKernelGGL((k_conv_obs_sep<TY_, WR_>), g, dim3(256), c->ob_lds, st, k, c->d_obs, \
+                       d_model, c->d_partial, c->kpad, c->nrank)
+    if (c->ob_ty == 32) { if (d_model) SLAM_OBS(32, true); else SLAM_OBS(32, false); }
+    else                { if (d_model) SLAM_OBS(16, true); else SLAM_OBS(16, false); }
+#undef SLAM_OBS
+    const int nblk = (int)(g.x * g.y) * k.nv;
+    Timed t2_(c, KID_FINALIZE, st);
+    hipLaunchKernelGGL(k_sum_chi2, dim3(nw), dim3(256), 0, st, k, c->d_partial, nblk,
+                       c->d_stats, d_chi2);
     HIP_TRY(c, hipGetLastError());
     return SLAMHIP_OK;
   }
@@ -1957,6 +2055,24 @@ int slamhip_create(const slamhip_desc* d, slamhip_ctx** out) {
   while (c->wgroup > 1 && (long long)c->wgroup * k.nv > 32768) --c->wgroup;
   c->rg_grid = dim3((k.nx + RED_THREADS - 1) / RED_THREADS, (k.ny + RG_ROWS - 1) / RG_ROWS, k.nv);
   c->red_blocks = (int)(c->rg_grid.x * c->rg_grid.y * c->rg_grid.z);
+  if (d->mom0decon && c->nrank >= 1) {
+    for (int ty : {32, 16}) {
+      const size_t need = ((size_t)(ty + K - 1) * ((C2_TX + K - 1) | 1) +
+                           (size_t)(ty + K - 1) * (C2_TX + 1)) * sizeof(double);
+      if (need <= 150 * 1024) { c->ob_ty = ty; c->ob_lds = need; break; }
+    }
+    if (c->ob_ty == 32) {
+      HIP_TRY(c, hipFuncSetAttribute((const void*)k_conv_obs_sep<32, true>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->ob_lds));
+      HIP_TRY(c, hipFuncSetAttribute((const void*)k_conv_obs_sep<32, false>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->ob_lds));
+    } else if (c->ob_ty == 16) {
+      HIP_TRY(c, hipFuncSetAttribute((const void*)k_conv_obs_sep<16, true>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->ob_lds));
+      HIP_TRY(c, hipFuncSetAttribute((const void*)k_conv_obs_sep<16, false>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->ob_lds));
+    }
+  }
   c->ob_grid = dim3((k.nx + C2_TX - 1) / C2_TX, (k.ny + C2_TY - 1) / C2_TY, k.nv);
   c->ob_blocks = (int)(c->ob_grid.x * c->ob_grid.y * c->ob_grid.z);
   const size_t max_blocks = std::max<size_t>(std::max<size_t>(c->red_blocks, c->ob_blocks),

@@ -33,8 +33,9 @@ def axes(N, NV):
 
 
 def make_fit(config='C3', bpa=0.0, seed=12345, N=None, NV=None, beam_px=None,
-             verbose=False, max_scratch_bytes=0):
-    """Return a `ChannelFit` with a SYN-v1 cube loaded and `makegrid` done."""
+             verbose=False, max_scratch_bytes=0, scaling='uniform'):
+    """Return a `ChannelFit` with a SYN-v1 cube loaded and `makegrid` done.
+    The data are the same for every `scaling` (truth from the 'uniform' model)."""
     from .channelfit import ChannelFit
     n, nv, bmaj_px, bmin_px = CONFIGS[config] if config in CONFIGS else (N, NV, *beam_px)
     if N is not None:
@@ -58,6 +59,8 @@ def make_fit(config='C3', bpa=0.0, seed=12345, N=None, NV=None, beam_px=None,
         rng = np.random.default_rng(seed)
         data = truth + rng.normal(0.0, SIGMA, truth.shape)
         fit.close()
+        if scaling != 'uniform':
+            fit = ChannelFit(scaling=scaling, progressbar=False)
         fit.set_cube(x, y, v, data, bmaj_px * dpix, bmin_px * dpix, bpa, SIGMA)
         fit.makegrid(cubefits=None, **kw)
     return fit

@@ -96,6 +96,11 @@ def test_gpu_model_and_chi2_match_reference(cfg, sc):
     # batch split / order independence, bitwise
     assert np.array_equal(fit.chi2_batch(P[::-1])[::-1], chi2)
     assert np.array_equal(np.array([fit.chi2_batch(p[None])[0] for p in P]), chi2)
+    # the direct K x K taps (conv_mode 1) and the factorised beam agree
+    fit.engine.set_conv_mode(1)
+    np.testing.assert_allclose(fit.chi2_batch(P), chi2, rtol=1e-11)
+    np.testing.assert_allclose(fit.chi2_batch(P), ref, rtol=1e-9)
+    fit.engine.set_conv_mode(0)
     for n in names:
         pre = f'{sc}_vec_{n}_'
         p = dict(zip(fit.paramkeys, m[pre + 'p']))
