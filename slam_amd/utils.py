@@ -330,6 +330,56 @@ def emcee_corner(bounds, log_prob_fn, args: list = [],
     return out
 
 
+def dynesty_corner(bounds, log_prob_fn, args: list = [], labels: list = None,
+                   figname: str = None, show_corner: bool = False,
+                   return_evidence: bool = False, simpleoutput: bool = True,
+                   wt_kwargs=None, vectorize: bool = False):
+    """Dynamic nested sampling in a box prior (reference utils.py:122-174): same
+    arguments and return values.  `vectorize=True`: `log_prob_fn` takes
+    p[nw, ndim] (the GPU likelihoods do); dynesty proposes one point at a time,
+    so the batch has one row.  Needs dynesty, which is optional: without it this
+    raises ImportError instead of substituting another sampler."""
+    try:
+        from dynesty import DynamicNestedSampler as DNS
+        from dynesty import utils as dyfunc
+    except ImportError as e:
+        raise ImportError('dynesty_corner needs the dynesty package '
+                          '(not installed); emcee_corner has a built-in sampler') from e
+    plim = np.array(bounds, dtype=float)
+    ndim = len(plim[0])
+    if vectorize:
+        def lnlike(p):
+            return float(np.asarray(log_prob_fn(np.atleast_2d(p), *args))[0])
+    else:
+        def lnlike(p):
+            return log_prob_fn(p, *args)
+
+    def ptform(u):
+        return plim[0] + (plim[1] - plim[0]) * u
+    dsampler = DNS(lnlike, ptform, ndim)
+    dsampler.run_nested(print_progress=False, wt_kwargs=wt_kwargs)
+    results = dsampler.results
+    if (figname is not None) & (show_corner == True):        # noqa: E712 (as the reference)
+        import matplotlib.pyplot as plt
+        from dynesty import plotting as dyplot
+        cfig, _ = dyplot.cornerplot(results, labels=labels, quantiles=[0.16, 0.5, 0.84])
+        cfig.savefig(figname)
+        plt.show()
+    weights = results.importance_weights()
+    quantiles = [dyfunc.quantile(samps, [0.16, 0.5, 0.84], weights=weights)
+                 for samps in results.samples.T]
+    if return_evidence:
+        evidence = np.exp(results.logz[-1])
+        print(f'Evidence: {evidence:.2e} +/- {evidence * results.logzerr[-1]:.2e}')
+    if simpleoutput:
+        pmid = np.array(quantiles).T[1]
+        perr = np.array([(q[2] - q[0]) * 0.5 for q in quantiles])
+        return [pmid, perr]
+    popt = results.samples[np.argmax(results.logl), :]
+    plow, pmid, phigh = np.array(quantiles).T
+    return [popt, plow, pmid, phigh]
+
+
 def _corner_plot(flat, popt, r_c, labels, figname, show):
     try:
         import corner
