@@ -39,7 +39,19 @@ def main():
                     help="ChannelFit scaling (C2-C4); the headline metric is 'uniform'")
     ap.add_argument('--cpu-evals', type=int, default=1,
                     help='oracle evaluations timed for cpu_baseline (0 = skip)')
+    ap.add_argument('--cpu-procs', type=int, default=-1,
+                    help='processes of the multi-core CPU baseline (-1 = auto: OMP_NUM_THREADS '
+                         'capped at 16; 0 = skip); runs before the GPU is touched')
+    ap.add_argument('--cpu-worker', type=int, default=-1, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.cpu_worker >= 0:        # one process of the multi-core CPU baseline
+        print(_cpu_worker((args.config, args.bpa, args.scaling, args.cpu_worker, args.cpu_evals)))
+        return
+
+    multi = None
+    if (int(os.environ.get('WORLD_SIZE', 1)) == 1 and args.cpu_evals > 0 and args.cpu_procs != 0
+            and args.config != 'P5'):
+        multi = cpu_baseline_multi(args)
 
     import torch
     import torch.distributed as dist
@@ -150,6 +162,8 @@ def main():
         }
         if world == 1 and args.cpu_evals > 0:
             out['cpu_baseline'] = cpu_baseline(fit, P, chi2, args.cpu_evals)
+            if multi is not None:
+                out['cpu_baseline']['all_cores'] = multi
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
@@ -254,6 +268,64 @@ def cpu_baseline_pv(kw, Q, lnp_gpu, nevals):
             'sample': f'first {nevals} of the {len(Q)} walkers, oracle/pvfitting_oracle.py '
                       '(numpy+scipy, single process)',
             'seconds': dt, 'max_rel_err_vs_gpu': err}
+
+
+def _cpu_worker(job):
+    """One process of the multi-core CPU baseline: its own oracle setup on a
+    noise cube of the workload's shape (the cost does not depend on the data
+    values), then `nevals` likelihood evaluations."""
+    config, bpa, scaling, seed, nevals = job
+    from oracle import channelfit_oracle as orc
+    from slam_amd import synth
+    n, nv, bmaj_px, bmin_px = synth.CONFIGS[config]
+    x, y, v, dpix = synth.axes(n, nv)
+    data = np.random.default_rng(seed).normal(0.0, synth.SIGMA, (nv, n, n))
+    s = orc.make_setup(x, y, v, data, bmaj=bmaj_px * dpix, bmin=bmin_px * dpix, bpa=bpa,
+                       sigma=synth.SIGMA, pa=2.0, incl=60.0, rmax=synth.RMAX, signmajor=1,
+                       signminor=1, scaling=scaling)
+    P = synth.walkers(1024)[seed * nevals:(seed + 1) * nevals]
+    t0 = time.perf_counter()
+    for p in P:
+        orc.chi2_of(s, p)
+    return time.perf_counter() - t0
+
+
+def cpu_baseline_multi(args):
+    """The reference's only parallel mode is one walker per process
+    (utils.py:50-55): P independent oracle processes, one evaluation each per
+    `--cpu-evals`, timed as a whole.  Runs before this process initialises the
+    GPU; the workers are separate `python bench.py --cpu-worker i` processes."""
+    import subprocess
+    procs = args.cpu_procs
+    if procs < 0:
+        procs = min(16, int(os.environ.get('OMP_NUM_THREADS', os.cpu_count() or 1)))
+    if procs < 2:
+        return None
+    env = dict(os.environ, OPENBLAS_NUM_THREADS='1', OMP_NUM_THREADS='1', MKL_NUM_THREADS='1')
+    cmd = [sys.executable, os.path.abspath(__file__), '--config', args.config, '--bpa',
+           str(args.bpa), '--scaling', args.scaling, '--cpu-evals', str(args.cpu_evals)]
+    t0 = time.perf_counter()
+    kids = [subprocess.Popen(cmd + ['--cpu-worker', str(i)], stdout=subprocess.PIPE,
+                             stderr=subprocess.DEVNULL, env=env, text=True) for i in range(procs)]
+    inner = []
+    try:
+        for k in kids:
+            out, _ = k.communicate(timeout=600)
+            if k.returncode != 0:
+                return None
+            inner.append(float(out.strip().splitlines()[-1]))
+    except (subprocess.TimeoutExpired, ValueError, IndexError):
+        for k in kids:
+            if k.poll() is None:
+                k.kill()
+        return None
+    wall = time.perf_counter() - t0
+    return {'value': procs * args.cpu_evals / max(inner), 'unit': 'evals/s', 'cores': procs,
+            'kind': 'port',
+            'sample': f'{procs} processes x {args.cpu_evals} evaluation(s), each with its own '
+                      'oracle setup on a noise cube of the same shape; rate = evaluations / '
+                      'slowest process (setup excluded)',
+            'seconds': max(inner), 'wall_seconds_with_setup': wall}
 
 
 def measured_traffic(kernel, args, eng):
