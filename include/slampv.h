@@ -123,14 +123,16 @@ int slampv_mockpvd(slampv_ctx* ctx, const double* params, double* major_out,
 
 /* Parity taps.  _own: level `level`'s own column sums, summed over z and not
  * yet multiplied by dz or divided by the global density maximum (rho2tau,
- * precalculation.py:136-144), [nv][ny_l][nx_l].  _tau: the nested optical-depth
+ * precalculation.py:136-144), [nv][ny_l][nx_l]; NaN marks the columns that are
+ * never computed because the nested add (mockpvd.py:272-277, diagonal
+ * sub-cells only) cannot carry them to level 0.  _tau: the nested optical-depth
  * cube on level 0 after the optional spectral smoothing (mockpvd.py:279-314),
  * [nv][ny0][nx0]. */
 int slampv_own_tau(slampv_ctx* ctx, const double* params, int axis, int level,
                    double* out);
 int slampv_tau(slampv_ctx* ctx, const double* params, int axis, double* out);
 
-/* Introspection: cells that can contribute (both axes), walkers per launch
+/* Introspection: cells that can contribute and are computed (both axes), walkers per launch
  * group, column tasks per walker. */
 int slampv_info(slampv_ctx* ctx, int64_t* live_cells, int32_t* walkers_per_group,
                 int32_t* tasks_per_walker);

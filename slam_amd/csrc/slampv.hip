@@ -28,6 +28,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <limits>
 #include <string>
 #include <vector>
 
@@ -43,6 +44,8 @@ constexpr int NT = 256;         // threads of the small kernels
 
 struct LevelK {
   int nx, ny, nz, ncol;
+  int nused;                    // columns whose sums can reach level 0 (see `used` below)
+  const int* used;              // [nused] their pixel indices y*nx+x, ascending
   int bx0, bx1, by0, by1, nsub;
   int nchunk, zlen;             // z split of this level's columns
   double dz;
@@ -51,7 +54,7 @@ struct LevelK {
   const double* er[2];
   const double* et[2];
   const double* ep[2];
-  long long own_off[2];         // offset of [chunk][nv][ncol] inside one walker's own buffer
+  long long own_off[2];         // offset of [chunk][nv][nused] inside one walker's own buffer
 };
 
 struct Task { int axis, level, col0, chunk; };
@@ -152,8 +155,9 @@ __global__ __launch_bounds__(64 * TAU_WAVES) void k_pv_tau(PvK k, const Task* __
   const int w = order[slot];
   const LevelK& L = k.lv[t.level];
   const WalkerPV q = wk[w];
-  const int col = t.col0 + lane;
-  const bool active = col < L.ncol;
+  const int ci = t.col0 + lane;               // index into the level's used-column list
+  const bool active = ci < L.nused;
+  const int col = active ? L.used[ci] : 0;
   const int z0 = t.chunk * L.zlen;
   const int z1 = min(L.nz, z0 + L.zlen);
   const double e0 = s_edge[0];
@@ -169,8 +173,8 @@ __global__ __launch_bounds__(64 * TAU_WAVES) void k_pv_tau(PvK k, const Task* __
     // the lane's own column of this chunk's image: cleared, then updated in
     // place whenever the running channel changes (same lane, program order)
     double* __restrict__ o = own + (size_t)w * k.own_stride + L.own_off[t.axis]
-        + (size_t)t.chunk * nv * L.ncol + col;
-    for (int v = 0; v < nv; ++v) o[(size_t)v * L.ncol] = 0.0;
+        + (size_t)t.chunk * nv * L.nused + ci;
+    for (int v = 0; v < nv; ++v) o[(size_t)v * L.nused] = 0.0;
     int cur = -1;
     double acc = 0.0;
     // ZU cells per trip: their constants and table lines are requested
@@ -217,7 +221,7 @@ __global__ __launch_bounds__(64 * TAU_WAVES) void k_pv_tau(PvK k, const Task* __
         while (bn < nv - 1 && vl >= s_edge[bn + 1]) ++bn;
         if (!(s_edge[bn] <= vl && vl < s_edge[bn + 1])) continue;   // outside every channel
         if (bn != cur) {
-          if (cur >= 0) o[(size_t)cur * L.ncol] += acc;
+          if (cur >= 0) o[(size_t)cur * L.nused] += acc;
           cur = bn;
           acc = rho;
         } else {
@@ -225,7 +229,7 @@ __global__ __launch_bounds__(64 * TAU_WAVES) void k_pv_tau(PvK k, const Task* __
         }
       }
     }
-    if (cur >= 0) o[(size_t)cur * L.ncol] += acc;
+    if (cur >= 0) o[(size_t)cur * L.nused] += acc;
   }
 }
 
@@ -244,16 +248,17 @@ __global__ __launch_bounds__(NT) void k_pv_nest(PvK k, const double* __restrict_
   int cur = 0;
   for (int l = k.nlevels - 1; l >= 0; --l) {
     const LevelK& L = k.lv[l];
-    const double* o = own + (size_t)w * k.own_stride + L.own_off[ax] + (size_t)v * L.ncol;
-    const size_t cstride = (size_t)k.nv * L.ncol;
+    const double* o = own + (size_t)w * k.own_stride + L.own_off[ax] + (size_t)v * L.nused;
+    const size_t cstride = (size_t)k.nv * L.nused;
     double* dst = buf[cur];
     const double* prev = buf[cur ^ 1];
     const bool has_child = l < k.nlevels - 1;
     const int n = L.nsub;
     const int nxc = has_child ? k.lv[l + 1].nx : 0;
-    for (int p = tid; p < L.ncol; p += NT) {
+    for (int ci = tid; ci < L.nused; ci += NT) {
+      const int p = L.used[ci];
       double s = 0.0;
-      for (int ch = 0; ch < L.nchunk; ++ch) s += o[ch * cstride + p];
+      for (int ch = 0; ch < L.nchunk; ++ch) s += o[ch * cstride + ci];
       s *= L.dz;
       if (has_child) {
         const int y = p / L.nx, x = p - y * L.nx;
@@ -720,6 +725,29 @@ int slampv_create(const slampv_desc* d, slampv_ctx** out) {
     if ((rc = dev_upload(c, &k.obs[0], d->obs_major, n))) return rc;
     if ((rc = dev_upload(c, &k.obs[1], d->obs_minor, n))) return rc;
   }
+  // Columns whose sums can reach level 0.  The nested add keeps only the
+  // DIAGONAL sub-cells of a refined pixel (mockpvd.py:272-277), so of the next
+  // level's pixels only (Y*n+i, X*n+i), i < n, of a pixel (Y, X) that is itself
+  // kept are ever read: the others are neither computed nor stored.
+  std::vector<std::vector<int>> used(d->nlevels);
+  {
+    std::vector<char> mark, next;
+    for (int l = 0; l < d->nlevels; ++l) {
+      const slampv_level& S = d->levels[l];
+      if (l == 0) mark.assign((size_t)S.nx * S.ny, 1); else mark.swap(next);
+      for (int p = 0; p < S.nx * S.ny; ++p) if (mark[p]) used[l].push_back(p);
+      if (l + 1 < d->nlevels) {
+        const slampv_level& Cn = d->levels[l + 1];
+        next.assign((size_t)Cn.nx * Cn.ny, 0);
+        for (int y = S.by0; y <= S.by1; ++y)
+          for (int x = S.bx0; x <= S.bx1; ++x) {
+            if (!mark[(size_t)y * S.nx + x]) continue;
+            for (int i = 0; i < S.nsub; ++i)
+              next[(size_t)((y - S.by0) * S.nsub + i) * Cn.nx + (x - S.bx0) * S.nsub + i] = 1;
+          }
+      }
+    }
+  }
   // levels, column tasks
   std::vector<Task> tasks;
   long long off = 0;
@@ -728,6 +756,8 @@ int slampv_create(const slampv_desc* d, slampv_ctx** out) {
     const slampv_level& S = d->levels[l];
     LevelK& L = k.lv[l];
     L.nx = S.nx; L.ny = S.ny; L.nz = S.nz; L.ncol = S.nx * S.ny;
+    L.nused = (int)used[l].size();
+    if ((rc = dev_upload(c, &L.used, used[l].data(), used[l].size()))) return rc;
     L.bx0 = S.bx0; L.bx1 = S.bx1; L.by0 = S.by0; L.by1 = S.by1; L.nsub = S.nsub;
     L.dz = S.dz;
     L.nchunk = (S.nz + ZCHUNK - 1) / ZCHUNK;
@@ -740,11 +770,12 @@ int slampv_create(const slampv_desc* d, slampv_ctx** out) {
       if ((rc = dev_upload(c, &L.er[a], S.elos_r[a], n))) return rc;
       if ((rc = dev_upload(c, &L.et[a], S.elos_t[a], n))) return rc;
       if ((rc = dev_upload(c, &L.ep[a], S.elos_p[a], n))) return rc;
-      for (size_t i = 0; i < n; ++i) c->live_cells += S.idx_t[a][i] >= 0;
+      for (int p : used[l])
+        for (int z = 0; z < S.nz; ++z) c->live_cells += S.idx_t[a][(size_t)z * L.ncol + p] >= 0;
       L.own_off[a] = off;
-      off += (long long)L.nchunk * d->nv * L.ncol;
+      off += (long long)L.nchunk * d->nv * L.nused;
       for (int ch = 0; ch < L.nchunk; ++ch)
-        for (int c0 = 0; c0 < L.ncol; c0 += 64) tasks.push_back({a, l, c0, ch});
+        for (int c0 = 0; c0 < L.nused; c0 += 64) tasks.push_back({a, l, c0, ch});
     }
   }
   k.own_stride = off;
@@ -869,15 +900,20 @@ int slampv_own_tau(slampv_ctx* c, const double* params, int axis, int level, dou
   int rc = host_batch(c, params, 1, nullptr, nullptr);
   if (rc) return rc;
   const LevelK& L = c->k.lv[level];
-  const size_t n = (size_t)c->k.nv * L.ncol;
-  std::vector<double> tmp(n * L.nchunk);
+  const size_t nu = (size_t)c->k.nv * L.nused;
+  std::vector<double> tmp(nu * L.nchunk);
+  std::vector<int> used(L.nused);
   HIP_TRY(c, hipMemcpy(tmp.data(), c->d_own + L.own_off[axis], tmp.size() * sizeof(double),
                        hipMemcpyDeviceToHost));
-  for (size_t i = 0; i < n; ++i) {
-    double s = 0.0;
-    for (int ch = 0; ch < L.nchunk; ++ch) s += tmp[ch * n + i];
-    out[i] = s;
-  }
+  HIP_TRY(c, hipMemcpy(used.data(), L.used, used.size() * sizeof(int), hipMemcpyDeviceToHost));
+  const double nan = std::numeric_limits<double>::quiet_NaN();
+  for (size_t i = 0; i < (size_t)c->k.nv * L.ncol; ++i) out[i] = nan;
+  for (int v = 0; v < c->k.nv; ++v)
+    for (int ci = 0; ci < L.nused; ++ci) {
+      double s = 0.0;
+      for (int ch = 0; ch < L.nchunk; ++ch) s += tmp[ch * nu + (size_t)v * L.nused + ci];
+      out[(size_t)v * L.ncol + used[ci]] = s;
+    }
   return SLAMPV_OK;
 }
 
