@@ -23,7 +23,7 @@ def short(name):
 
 
 def counter_rows(d, counter):
-    f = glob.glob(os.path.join(d, '*', '*_counter_collection.csv'))[0]
+    f = max(glob.glob(os.path.join(d, '*', '*_counter_collection.csv')), key=os.path.getmtime)
     per = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         if r['Counter_Name'] == counter:
@@ -35,7 +35,7 @@ def main():
     tag = sys.argv[1]
     src = f'gpurun_out/prof_{tag}'
     os.makedirs('profiles', exist_ok=True)
-    stats = glob.glob(os.path.join(src, 'trace', '*', '*_kernel_stats.csv'))[0]
+    stats = max(glob.glob(os.path.join(src, 'trace', '*', '*_kernel_stats.csv')), key=os.path.getmtime)
     shutil.copy(stats, f'profiles/{tag}_kernel_stats.csv')
     bench = [l for l in open(os.path.join(src, 'bench.json')) if l.startswith('{')][-1]
     open(f'profiles/{tag}_bench.json', 'w').write(bench)
