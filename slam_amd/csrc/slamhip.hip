@@ -40,6 +40,8 @@ constexpr int CH = 16;                       // channels accumulated in register
 constexpr int CONV_TX = 64;                  // conv tile width (= one wave)
 constexpr int CONV_R = 8;                    // outputs per thread along the tap axis
 constexpr int RED_THREADS = 256;
+constexpr int IDX_UNITS = 4;          // fast-index guard, in units of 2^-20
+constexpr double IDX_BIAS = 22.5 * 1048576.0 + IDX_UNITS + 6755399441055744.0;   // 22.5*2^20 + guard + 1.5*2^52
 constexpr int MAX_RANK = 24;                 // beam outer-product terms the fused kernel accepts
 constexpr unsigned LEAF_PAD = 0xffffffffu;    // slot without a sample
 constexpr int FLAG_MAX = 512;                // occupancy bytes one conv window may span
@@ -56,6 +58,8 @@ struct FitK {
   double dv, sigma, pixperbeam, incl0, signmajor, signminor, vunit;
   double ssq_data;      // sum(data_valid^2), fixed per fit
   int data_has_nan;
+  int fast_idx;         // k_profile may use the fixed-point table index
+  double* tk;           // per-group scratch [walker][nvpad]: v_k * rinv * 2^20 (k_prep -> k_profile)
   const double* Xnest0;
   const double* Ynest0;
   const double* xneed;
@@ -180,6 +184,13 @@ __global__ void k_prep(FitK g, const double* __restrict__ params, int nw,
       if (t == 0 || t == PROF_N) val = 0.0;
     }
     o.prof[t] = val;
+  }
+  {
+    // channel velocities in units of 2^-20 table steps, for k_profile's
+    // fixed-point index; padding channels land on prof[44] = 0
+    const double R = (1.0 / (g.dv * d)) * 1048576.0;
+    for (int k = t; k < g.nvpad; k += blockDim.x)
+      g.tk[(long long)w * g.nvpad + k] = k < g.nv ? g.vpad[k] * R : 1000.0 * 1048576.0;
   }
   if (t == 0) {
     const double Mstar = p[0], Rc = p[1], h1 = p[3], h2v = p[4], pI = p[5];
@@ -381,6 +392,7 @@ __device__ inline unsigned wave_or(unsigned v) {
 // channel, 32x8 tile) gets an occupancy byte and only occupied tiles are
 // written.  Consumers either honour the flags (k_conv_chi2) or are handed a
 // pre-zeroed buffer (dense taps).
+template <bool FAST>
 __global__ void __launch_bounds__(256)
 k_profile(FitK g, const WalkerK* __restrict__ wk, const double2* __restrict__ geom,
           double* __restrict__ iunif, unsigned char* __restrict__ flags, int ftx, int fty,
@@ -427,7 +439,14 @@ k_profile(FitK g, const WalkerK* __restrict__ wk, const double2* __restrict__ ge
     bool hit = false;
     double vks[CH];                                       // this block's channel velocities (scalar)
 #pragma unroll
-    for (int c = 0; c < CH; ++c) vks[c] = vk[c];
+    for (int c = 0; c < CH; ++c) vks[c] = FAST ? 0.0 : vk[c];
+    // fast table index (FAST: create checked that every |t| of a lit block is
+    // below 2^11): this block's channels as k_prep scaled them, block-uniform
+    const double R = rinv * 1048576.0;
+    const double* __restrict__ tkp = g.tk + (long long)wi * g.nvpad + cix * CH;
+    double tks[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) tks[c] = FAST ? tkp[c] : 0.0;
     double2 q[4], qn[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s)
@@ -451,17 +470,35 @@ k_profile(FitK g, const WalkerK* __restrict__ wk, const double2* __restrict__ ge
         // iv by < 1e-12); lanes within IDX_GUARD of an integer redo it exactly
         int idx[CH];
         bool near = false;
+        if (FAST) {
+          // t*2^20 rounded to an integer in the low mantissa bits of
+          // (t*2^20 + 1.5*2^52): idx = u >> 20, fraction = u & (2^20-1).  The
+          // sum carries at most one unit (2^-20) of rounding error; lanes within
+          // IDX_UNITS of an integer redo the index exactly.
+          // (the bias also carries +IDX_UNITS: "near" is then fraction < 2*IDX_UNITS,
+          // and u >> 20 is the index whenever the lane is not near)
+          const double base = fma(-o, R, IDX_BIAS);
+          unsigned lowest = 0xFFFFFu;
 #pragma unroll
-        for (int c = 0; c < CH; ++c) {
-          const double t = fma(vks[c] - o, rinv, 22.5);
-          near |= fabs(t - rint(t)) < IDX_GUARD;
-          idx[c] = (int)t;                                // saturating; NaN -> 0
+          for (int c = 0; c < CH; ++c) {
+            const int u = __double2loint(tks[c] + base);
+            lowest = min(lowest, (unsigned)u & 0xFFFFFu);
+            idx[c] = u >> 20;
+          }
+          near = lowest < 2u * IDX_UNITS;
+        } else {
+#pragma unroll
+          for (int c = 0; c < CH; ++c) {
+            const double t = fma(vks[c] - o, rinv, 22.5);
+            near |= fabs(t - rint(t)) < IDX_GUARD;
+            idx[c] = (int)t;                              // saturating; NaN -> 0
+          }
         }
         if (near) {
           // iv = ((v_valid - vlos) - voff) / dv / prof_d + prof_n//2 + 0.5   (:461-462)
 #pragma unroll
           for (int c = 0; c < CH; ++c) {
-            double v = vks[c] - vl;
+            double v = (FAST ? vk[c] : vks[c]) - vl;
             v = v - voff;
             idx[c] = (int)(v / g.dv / w.prof_d + 22.0 + 0.5);
           }
@@ -1717,9 +1754,14 @@ int run_model(slamhip_ctx* c, const double* d_params, int nw, hipStream_t st, bo
     Timed t_(c, KID_PROFILE, st);
     const int tgroups = (c->ftx * c->fty + 7) / 8;
     dim3 g2((unsigned)tgroups * 8u * (unsigned)(k.nvpad / CH) * (unsigned)nw, 1, 1);
-    hipLaunchKernelGGL(k_profile, g2, dim3(256), 0, st, k, c->d_wk, c->d_geom,
-                       c->d_iunif, c->d_flags, c->ftx, c->fty, c->d_winflag, (int)c->fz_grid.x, (int)c->fz_grid.y,
-                       c->fz_sx, c->fz_sy);
+    if (k.fast_idx)
+      hipLaunchKernelGGL(k_profile<true>, g2, dim3(256), 0, st, k, c->d_wk, c->d_geom,
+                         c->d_iunif, c->d_flags, c->ftx, c->fty, c->d_winflag, (int)c->fz_grid.x, (int)c->fz_grid.y,
+                         c->fz_sx, c->fz_sy);
+    else
+      hipLaunchKernelGGL(k_profile<false>, g2, dim3(256), 0, st, k, c->d_wk, c->d_geom,
+                         c->d_iunif, c->d_flags, c->ftx, c->fty, c->d_winflag, (int)c->fz_grid.x, (int)c->fz_grid.y,
+                         c->fz_sx, c->fz_sy);
   }
   HIP_TRY(c, hipGetLastError());
   return SLAMHIP_OK;
@@ -1935,6 +1977,12 @@ int slamhip_create(const slamhip_desc* d, slamhip_ctx** out) {
     }
     cmin[b] = lo; cmax[b] = hi;
   }
+  // |t| <= 45.1 + 11 * (velocity span of a block in channel widths) for every
+  // channel of a block that holds emission (rinv <= 11/|dv|); the fixed-point
+  // index needs |t| < 2^11
+  k.fast_idx = 1;
+  for (int b = 0; b < k.nvpad / CH; ++b)
+    if (!(std::fabs(cmax[b] - cmin[b]) <= 150.0 * std::fabs(k.dv))) k.fast_idx = 0;
 
   // --- beam: separable when it is an outer product of its central row/col --
   const int cc = k.ngauss;
@@ -2086,6 +2134,7 @@ int slamhip_create(const slamhip_desc* d, slamhip_ctx** out) {
   if (d->mom0decon && (rc = dev_alloc(c, &c->d_obs, W * ncube))) return rc;
   if ((rc = dev_alloc(c, &c->d_partial, W * max_blocks * 3))) return rc;
   if ((rc = dev_alloc(c, &c->d_stats, W * 6))) return rc;
+  if ((rc = dev_alloc(c, &k.tk, W * (size_t)k.nvpad))) return rc;
   if ((rc = dev_alloc(c, &c->d_chi2, W))) return rc;
   if ((rc = dev_alloc(c, &c->d_cellx, W * k.nx))) return rc;
   if ((rc = dev_alloc(c, &c->d_fracx, W * k.nx))) return rc;

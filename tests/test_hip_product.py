@@ -206,3 +206,42 @@ def st_conv(s, p):
     st = {}
     orc.cubemodel(s, p, stages=st)
     return st['Iconv']
+
+
+def test_wide_velocity_gap_uses_exact_index_path():
+    """Two velocity windows 184 channels apart inside one 16-channel block:
+    beyond the span the fixed-point table index of k_profile is checked for at
+    create time, so the kernel's plain double-precision index path runs; it
+    must agree with the oracle like the fast one."""
+    from slam_amd.channelfit import ChannelFit
+    n, nv = 24, 200
+    dpix = 12.
+    x = -(np.arange(n) - n // 2) * dpix
+    y = (np.arange(n) - n // 2) * dpix
+    v = (np.arange(nv) - nv / 2 + 0.5) * 0.04
+    data = np.random.default_rng(8).normal(0, 1e-3, (nv, n, n))
+    vlim = (v[0] - 0.01, v[7] + 0.01, v[-8] - 0.01, v[-1] + 0.01)
+    kw = dict(bmaj=4 * dpix, bmin=3 * dpix, bpa=0., sigma=1e-3, pa=10., incl=50., rmax=120.,
+              vlim=vlim, signmajor=1, signminor=1)
+    fit = ChannelFit(progressbar=False)
+    fit.set_cube(x, y, v, data, kw['bmaj'], kw['bmin'], kw['bpa'], kw['sigma'])
+    quiet(fit.makegrid, cubefits=None, pa=kw['pa'], incl=kw['incl'], rmax=kw['rmax'],
+          vlim=vlim, signmajor=1, signminor=1)
+    assert len(fit.v_valid) == 16
+    s = orc.make_setup(x, y, v, data, **kw)
+    rng = np.random.default_rng(9)
+    P = np.zeros((4, 13))
+    P[:, 0] = rng.uniform(0.2, 1.0, 4)      # Mstar
+    P[:, 1] = rng.uniform(40, 150, 4)       # Rc
+    P[:, 2] = [0.4, 0.1, 0.02, 0.3]         # cs
+    P[:, 3] = rng.uniform(0, 0.4, 4)
+    P[:, 4] = rng.uniform(0, 0.4, 4)
+    P[:, 5] = rng.uniform(0, 2, 4)
+    ref = np.array([orc.chi2_of(s, p) for p in P])
+    np.testing.assert_allclose(fit.chi2_batch(P), ref, rtol=1e-9)
+    g = fit.engine.iunif(P[0])
+    st = {}
+    orc.cubemodel(s, P[0], stages=st)
+    assert np.array_equal(g != 0, st['Iunif'] != 0)
+    assert _golden.relmax(g, st['Iunif']) < 1e-12
+    fit.close()
