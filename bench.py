@@ -42,6 +42,8 @@ def main():
     ap.add_argument('--cpu-procs', type=int, default=-1,
                     help='processes of the multi-core CPU baseline (-1 = auto: OMP_NUM_THREADS '
                          'capped at 16; 0 = skip); runs before the GPU is touched')
+    ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
+                    help='process-group backend; gloo only to rehearse N>1 on a box with fewer GPUs')
     ap.add_argument('--cpu-worker', type=int, default=-1, help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_worker >= 0:        # one process of the multi-core CPU baseline
@@ -60,9 +62,14 @@ def main():
     local = int(os.environ.get('LOCAL_RANK', 0))
     if world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run')
+    if args.backend == 'gloo':          # rehearsal: ranks may share a GPU
+        local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     if world > 1:
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        else:
+            dist.init_process_group('gloo')
 
     from slam_amd import synth
     from slam_amd.sharding import ShardedLikelihood
