@@ -36,7 +36,7 @@
 
 namespace {
 
-constexpr int ZCHUNK = 72;      // longest z run one lane walks
+constexpr int ZCHUNK = 288;     // longest z run one lane walks
 constexpr int ZU = 8;           // cells in flight per lane
 constexpr int TAU_WAVES = 4;    // walkers (waves) per k_pv_tau workgroup
 constexpr int MAX_LEVELS = 12;

@@ -291,3 +291,20 @@ def test_all_zero_model_gives_zero_lnprob():
     m.set_observations(obs[0], obs[1], 0.5, 2.0)
     lnp = m.lnprob_batch([[0.6, 70., 0.5, 2., 5., 1.]], 45., None, 1., 0.5)
     assert lnp[0] == 0.0
+
+
+def test_long_line_of_sight_is_split_into_chunks():
+    """nz = 601 exceeds one lane's z run (288 cells): the column is summed in
+    three chunks that k_pv_nest adds in order.  Against the oracle."""
+    x = (np.arange(9) - 4) * 10.
+    z = (np.arange(601) - 300) * 4.
+    v = (np.arange(14) - 6.5) * 0.35
+    beam = [22., 15., 40.]
+    kw = dict(nnest=[2], reslim=2, signmajor=1, signminor=1, pa_major=0., pa_minor=90.)
+    m = MockPVD(x, z, v, beam=beam, **kw)
+    s = O.make_setup(x, z, v, beam, incl=70., rc_first=55., linewidth=None,
+                     rout=float(np.max(z)), **kw)
+    for q in ((0.5, 55., 0.8, 3., 30.), (0.25, 130., 0.4, 40., 2.)):
+        major, minor = m.generate_mockpvd(*q, incl=70., rout=float(np.max(z)))
+        rm, rn = O.mockpvd(s, *q)
+        assert relmax(major, rm) < 1e-10 and relmax(minor, rn) < 1e-10
