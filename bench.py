@@ -247,10 +247,10 @@ def run_pv(args, rank, world, torch, dist):
 
 def pv_traffic(eng):
     """HBM bytes per k_pv_tau launch from the committed rocprofv3 PMC passes of
-    this same command (profiles/pv_traffic.json; FETCH_SIZE x2 + WRITE_SIZE, as
+    this same command (profiles/r1_pv_traffic.json; FETCH_SIZE x2 + WRITE_SIZE, as
     for the channelfit kernels), or null."""
     try:
-        t = json.load(open(os.path.join(ROOT, 'profiles', 'pv_traffic.json')))
+        t = json.load(open(os.path.join(ROOT, 'profiles', 'r1_pv_traffic.json')))
     except Exception:
         return None
     if t.get('_meta', {}).get('walkers_per_launch') != eng.walkers_per_group:
