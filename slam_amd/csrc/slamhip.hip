@@ -1287,26 +1287,66 @@ k_finalize(FitK g, const double* __restrict__ partial, int nblk,
 // pixel's spectrum is rescaled so that its moment 0 equals the deconvolved
 // observed one, and the beam is applied on the observed grid.
 // ---------------------------------------------------------------------------
-// k_mom0_scale: cube[w][k][p] <- nan_to_num(cube * mom0decon[p] / (sum_k cube * dv)),
-// a negative moment 0 counting as NaN (:522-525).  Thread per (walker, pixel).
+// k_regrid_mom0: regrid (:475-483) and per-pixel moment-0 scale (:521-525) in
+// one pass.  Thread per (walker, observed pixel): the bilinear value of every
+// channel is formed twice (once for the moment, once for the scaled output)
+// instead of storing the unscaled cube; Iunif tiles that k_profile left unlit
+// are never read (their occupancy byte is 0), so Iunif need not be cleared.
+// Also raises the occupancy byte of the pixel's k_conv_obs_sep tile.
 __global__ void __launch_bounds__(256)
-k_mom0_scale(FitK g, double* __restrict__ cube) {
+k_regrid_mom0(FitK g, const int* __restrict__ cellx, const double* __restrict__ fracx,
+              const int* __restrict__ celly, const double* __restrict__ fracy,
+              const double* __restrict__ iunif, const unsigned char* __restrict__ flags,
+              int ftx, int fty, double* __restrict__ cube,
+              unsigned char* __restrict__ tileflag, int tile_ty, int ntx, int nty) {
   const long long npix = (long long)g.ny * g.nx;
   const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
   if (p >= npix) return;
-  double* c = cube + (long long)blockIdx.y * g.nv * npix + p;
+  const int wi = blockIdx.y;
+  const int jy = (int)(p / g.nx), ix = (int)(p - (long long)jy * g.nx);
+  const int i1 = cellx[(long long)wi * g.nx + ix], i0 = celly[(long long)wi * g.ny + jy];
+  const double t1 = fracx[(long long)wi * g.nx + ix], t0 = fracy[(long long)wi * g.ny + jy];
+  const int n = g.nneed;
+  const bool nanq = i0 == -2 || i1 == -2;         // NaN query point
+  const bool inside = i0 >= 0 && i1 >= 0;         // fill_value = 0 outside
+  const long long ntile = (long long)ftx * fty;
+  int ta = 0, tb = 0, tc = 0, td = 0;
+  if (inside && !nanq) {
+    ta = (i0 / PT_Y) * ftx + i1 / PT_X;       tb = (i0 / PT_Y) * ftx + (i1 + 1) / PT_X;
+    tc = ((i0 + 1) / PT_Y) * ftx + i1 / PT_X; td = ((i0 + 1) / PT_Y) * ftx + (i1 + 1) / PT_X;
+  }
+  auto value = [&](int k) -> double {
+    if (nanq) return __builtin_nan("");
+    if (!inside) return 0.0;
+    const unsigned char* f = flags + ((long long)wi * g.nv + k) * ntile;
+    const unsigned char fa = f[ta], fb = f[tb], fc = f[tc], fd = f[td];
+    if (!(fa | fb | fc | fd)) return 0.0;
+    const double* c = iunif + (((long long)wi * g.nv + k) * n + i0) * n + i1;
+    const double v00 = fa ? c[0] : 0.0, v01 = fb ? c[1] : 0.0;
+    const double v10 = fc ? c[n] : 0.0, v11 = fd ? c[n + 1] : 0.0;
+    return v00 * (1 - t0) * (1 - t1) + v01 * (1 - t0) * t1 +
+           v10 * t0 * (1 - t1) + v11 * t0 * t1;     // scipy _rgi.py:478-482, as k_regrid
+  };
   double m0 = 0.0;
-  for (int k = 0; k < g.nv; ++k) m0 += c[(long long)k * npix];
+  for (int k = 0; k < g.nv; ++k) m0 += value(k);
   m0 = m0 * g.dv;
   if (m0 < 0.0) m0 = __builtin_nan("");
+  double* c = cube + (long long)wi * g.nv * npix + p;
+  if (m0 == 0.0) {                                 // every channel is 0: 0*dec/0 -> NaN -> 0
+    for (int k = 0; k < g.nv; ++k) c[(long long)k * npix] = 0.0;
+    return;
+  }
+  unsigned char* fl = tileflag
+      ? tileflag + (long long)wi * g.nv * ntx * nty + (jy / tile_ty) * ntx + ix / C2_TX : nullptr;
   const double dec = g.mom0decon[p];
   const double big = std::numeric_limits<double>::max();
   for (int k = 0; k < g.nv; ++k) {
-    double v = c[(long long)k * npix] * dec / m0;
+    double v = value(k) * dec / m0;
     if (v != v) v = 0.0;
     else if (v > big) v = big;
     else if (v < -big) v = -big;
     c[(long long)k * npix] = v;
+    if (fl && v != 0.0) fl[(long long)k * ntx * nty] = 1;
   }
 }
 
@@ -1377,69 +1417,149 @@ k_conv_obs(FitK g, const double* __restrict__ in, double* __restrict__ out,
 // sum of `nrank` outer products (exactly one for an axis-aligned Gaussian; the
 // leading singular triplets, tail < 1e-13, for a rotated one): per term a row
 // pass into an LDS intermediate and a column pass, 2K instead of K^2 taps.
-template <int TY, bool WRITE>
+template <int TY, int NIT, bool WRITE>
 __global__ void __launch_bounds__(256)
 k_conv_obs_sep(FitK g, const double* __restrict__ in, double* __restrict__ out,
-               double* __restrict__ partial, int kpad, int nrank) {
+               double* __restrict__ partial, int kpad, int nrank,
+               const unsigned char* __restrict__ tileflag, const double* __restrict__ empty_ss) {
   extern __shared__ double lds[];
-  constexpr int TX = C2_TX, RY = TY / 4;
+  constexpr int TX = C2_TX;
   const int K = g.kbeam, ng = g.ngauss, nx = g.nx, ny = g.ny;
-  const int rows = TY + K - 1, cols = TX + K - 1;
+  if (tileflag) {
+    // no emission in any tile under this window's halo: the model is 0 here and
+    // the residual sum is the tile's sum of data^2, computed once per fit by this
+    // same kernel on an all-zero cube (`empty_ss`)
+    const int ntx = gridDim.x, nty = gridDim.y;
+    const int fx0 = max((int)blockIdx.x * TX - ng, 0) / TX;
+    const int fx1 = min((int)blockIdx.x * TX + TX - 1 + ng, nx - 1) / TX;
+    const int fy0 = max((int)blockIdx.y * TY - ng, 0) / TY;
+    const int fy1 = min((int)blockIdx.y * TY + TY - 1 + ng, ny - 1) / TY;
+    const unsigned char* fl = tileflag + (long long)blockIdx.z * ntx * nty;
+    bool some = false;
+    const int nf = (fx1 - fx0 + 1) * (fy1 - fy0 + 1);
+    for (int e = threadIdx.x; e < nf; e += 256) {
+      const int fy = fy0 + e / (fx1 - fx0 + 1), fx = fx0 + e % (fx1 - fx0 + 1);
+      some |= fl[fy * ntx + fx] != 0;
+    }
+    if (!__syncthreads_or(some)) {
+      const long long blk1 = ((long long)(blockIdx.z % g.nv) * nty + blockIdx.y) * ntx + blockIdx.x;
+      const long long blk = ((long long)blockIdx.z * nty + blockIdx.y) * ntx + blockIdx.x;
+      if (threadIdx.x == 0) partial[blk] = empty_ss[blk1];
+      if (WRITE) {
+        const long long plane = (long long)ny * nx;
+        for (int e = threadIdx.x; e < TX * TY; e += 256) {
+          const int gy = blockIdx.y * TY + e / TX, gx = blockIdx.x * TX + (e & (TX - 1));
+          if (gx < nx && gy < ny) out[(long long)blockIdx.z * plane + (long long)gy * nx + gx] = 0.0;
+        }
+      }
+      return;
+    }
+  }
+  constexpr int R = 8;                  // outputs per thread along the tap axis
+  static_assert(TY % R == 0 && TY / R <= 4, "one 8-row block per wave");
+  // tile and intermediate are padded to the tap count rounded up to R (kpad):
+  // the sliding windows below read up to kpad+R-2 past their origin, against
+  // zero weights there
+  const int rows = TY + kpad - 1, cols = TX + kpad - 1;
   const int P = cols | 1, P2 = TX + 1;
   double* tile = lds;                   // [rows][P]
-  double* tmp = lds + rows * P;         // [rows][P2]
+  double* tmp = nrank > 1 ? lds + rows * P : lds;   // [rows][P2]; overlays the tile for one term
   const int tid = threadIdx.x;
   const long long plane = (long long)ny * nx;
   const int k = blockIdx.z % g.nv;
   const double* src = in + (long long)blockIdx.z * plane;
   const int x0 = blockIdx.x * TX, y0 = blockIdx.y * TY;
+  const int vrows = TY + K - 1, vcols = TX + K - 1;
   bool any = false;
   for (int e = tid; e < rows * P; e += 256) {
     const int rr = e / P, cc = e - rr * P;
     const int gy = y0 - ng + rr, gx = x0 - ng + cc;
     double v = 0.0;
-    if (cc < cols && gy >= 0 && gy < ny && gx >= 0 && gx < nx)
+    if (rr < vrows && cc < vcols && gy >= 0 && gy < ny && gx >= 0 && gx < nx)
       v = src[(long long)gy * nx + gx];
     any |= v != 0.0;
     tile[e] = v;
   }
   const bool live = __syncthreads_or(any) != 0;   // empty sky convolves to zero
-  const int tx = tid & 63, ty = tid >> 6;
-  double acc[RY];
+  const int lane = tid & 63, wv = tid >> 6;
+  double acc[R];
 #pragma unroll
-  for (int r = 0; r < RY; ++r) acc[r] = 0.0;
+  for (int r = 0; r < R; ++r) acc[r] = 0.0;
   if (live) {
+    const int nitem = rows * (TX / R);
     for (int rk = 0; rk < nrank; ++rk) {
       const double* wx = g.gx_pad + (long long)rk * kpad;
       const double* wy = g.gy_pad + (long long)rk * kpad;
       if (rk) __syncthreads();
-      for (int e = tid; e < rows * TX; e += 256) {
-        const int rr = e >> 6, xx = e & 63;
-        const double* row = tile + rr * P + xx;
-        double s = 0.0;
-        for (int u = 0; u < K; ++u) s = fma(wx[u], row[u], s);
-        tmp[rr * P2 + xx] = s;
+      // row pass: tmp[row][x] = sum_u wx[u] * tile[row][x+u]; an item is R
+      // neighbouring x of one row, lanes <-> rows (odd pitch: no bank conflicts).
+      // Results stay in registers across the barrier so that, for a one-term
+      // beam, the intermediate can overlay the tile.
+      double res[NIT][R];
+#pragma unroll
+      for (int q = 0; q < NIT; ++q) {
+        const int item = q * 256 + tid;
+#pragma unroll
+        for (int r = 0; r < R; ++r) res[q][r] = 0.0;
+        if (item < nitem) {
+          const int xb = item / rows, rr = item - xb * rows;
+          const double* row = tile + rr * P + xb * R;
+          double win[R];
+#pragma unroll
+          for (int r = 0; r < R - 1; ++r) win[r] = row[r];
+          for (int u0 = 0; u0 < kpad; u0 += R) {
+#pragma unroll
+            for (int qq = 0; qq < R; ++qq) {
+              win[(qq + R - 1) % R] = row[u0 + qq + R - 1];
+              const double w = wx[u0 + qq];
+#pragma unroll
+              for (int r = 0; r < R; ++r) res[q][r] = fma(w, win[(r + qq) % R], res[q][r]);
+            }
+          }
+        }
       }
       __syncthreads();
-      for (int u = 0; u < K; ++u) {
-        const double w = wy[u];
 #pragma unroll
-        for (int r = 0; r < RY; ++r)
-          acc[r] = fma(w, tmp[(ty + 4 * r + u) * P2 + tx], acc[r]);
+      for (int q = 0; q < NIT; ++q) {
+        const int item = q * 256 + tid;
+        if (item < nitem) {
+          const int xb = item / rows, rr = item - xb * rows;
+#pragma unroll
+          for (int r = 0; r < R; ++r) tmp[rr * P2 + xb * R + r] = res[q][r];
+        }
+      }
+      __syncthreads();
+      // column pass: wave wv owns output rows wv*R .. wv*R+R-1, lanes <-> x
+      if (wv < TY / R) {
+        const double* col = tmp + (wv * R) * P2 + lane;
+        double win[R];
+#pragma unroll
+        for (int r = 0; r < R - 1; ++r) win[r] = col[r * P2];
+        for (int u0 = 0; u0 < kpad; u0 += R) {
+#pragma unroll
+          for (int qq = 0; qq < R; ++qq) {
+            win[(qq + R - 1) % R] = col[(u0 + qq + R - 1) * P2];
+            const double w = wy[u0 + qq];
+#pragma unroll
+            for (int r = 0; r < R; ++r) acc[r] = fma(w, win[(r + qq) % R], acc[r]);
+          }
+        }
       }
     }
   }
-  const int gx = x0 + tx;
+  const int gx = x0 + lane;
   double ss = 0.0;
+  if (wv < TY / R) {
 #pragma unroll
-  for (int r = 0; r < RY; ++r) {
-    const int gy = y0 + ty + 4 * r;
-    if (gx < nx && gy < ny) {
-      const long long e = (long long)gy * nx + gx;
-      if (WRITE) out[(long long)blockIdx.z * plane + e] = acc[r];
-      const double d = g.data[(long long)k * plane + e] - acc[r];
-      const double q = d * d;
-      if (q == q) ss += q;
+    for (int r = 0; r < R; ++r) {
+      const int gy = y0 + wv * R + r;
+      if (gx < nx && gy < ny) {
+        const long long e = (long long)gy * nx + gx;
+        if (WRITE) out[(long long)blockIdx.z * plane + e] = acc[r];
+        const double d = g.data[(long long)k * plane + e] - acc[r];
+        const double q = d * d;
+        if (q == q) ss += q;
+      }
     }
   }
   __shared__ double sred[4];
@@ -1507,7 +1627,11 @@ struct slamhip_ctx {
   dim3 ob_grid{1, 1, 1};       // k_conv_obs grid for ONE walker (z = nv)
   int ob_blocks = 0;
   int ob_ty = 0;               // rows per k_conv_obs_sep tile (32 / 16), 0 = direct taps
+  int ob_nit = 0;              // row-pass items per thread of that variant
   size_t ob_lds = 0;
+  unsigned char* d_obflag = nullptr;  // [walker][nv][tiles] emission under k_conv_obs_sep tiles
+  double* d_obempty = nullptr;        // [nv][tiles] residual sum of an empty tile (= sum data^2)
+  int ob_nty = 0;
   double* d_partial = nullptr;
   double* d_stats = nullptr;
   double* d_chi2 = nullptr;
@@ -1773,16 +1897,18 @@ int run_model(slamhip_ctx* c, const double* d_params, int nw, hipStream_t st, bo
 int run_group_mom0(slamhip_ctx* c, const double* d_params, int nw, double* d_chi2,
                    double* d_model, bool convolving, hipStream_t st) {
   const FitK& k = c->k;
-  int rc = run_model(c, d_params, nw, st, true);
+  int rc = run_model(c, d_params, nw, st, false);
   if (rc) return rc;
   {
     Timed t_(c, KID_REGRID, st);
-    dim3 g4(c->rg_grid.x, c->rg_grid.y, c->rg_grid.z * nw);
-    hipLaunchKernelGGL((k_regrid<true>), g4, dim3(RED_THREADS), 0, st, k, c->d_cellx,
-                       c->d_fracx, c->d_celly, c->d_fracy, c->d_iunif, c->d_partial, c->d_obs);
     const long long npix = (long long)k.ny * k.nx;
-    hipLaunchKernelGGL(k_mom0_scale, dim3((unsigned)((npix + 255) / 256), nw), dim3(256), 0, st, k,
-                       c->d_obs);
+    const bool flagged = c->ob_ty && c->conv_mode == 0 && convolving;
+    if (flagged)
+      HIP_TRY(c, hipMemsetAsync(c->d_obflag, 0, (size_t)nw * k.nv * c->ob_grid.x * c->ob_nty, st));
+    hipLaunchKernelGGL(k_regrid_mom0, dim3((unsigned)((npix + 255) / 256), nw), dim3(256), 0, st, k,
+                       c->d_cellx, c->d_fracx, c->d_celly, c->d_fracy, c->d_iunif, c->d_flags,
+                       c->ftx, c->fty, c->d_obs, flagged ? c->d_obflag : (unsigned char*)nullptr,
+                       c->ob_ty ? c->ob_ty : 1, (int)c->ob_grid.x, c->ob_nty);
   }
   if (!convolving) {       // peaktounity on the observed grid (:531-532), single-vector product
     hipLaunchKernelGGL(k_peak_unity, dim3(k.nv * nw), dim3(256), 0, st, k, c->d_obs, d_model,
@@ -1793,11 +1919,12 @@ int run_group_mom0(slamhip_ctx* c, const double* d_params, int nw, double* d_chi
   if (c->ob_ty && c->conv_mode == 0) {
     Timed t_(c, KID_CONV, st);
     dim3 g(c->ob_grid.x, (k.ny + c->ob_ty - 1) / c->ob_ty, c->ob_grid.z * nw);
-#define SLAM_OBS(TY_, WR_)                                                                  \
-    hipLaunchKernelGGL((k_conv_obs_sep<TY_, WR_>), g, dim3(256), c->ob_lds, st, k, c->d_obs, \
-                       d_model, c->d_partial, c->kpad, c->nrank)
-    if (c->ob_ty == 32) { if (d_model) SLAM_OBS(32, true); else SLAM_OBS(32, false); }
-    else                { if (d_model) SLAM_OBS(16, true); else SLAM_OBS(16, false); }
+#define SLAM_OBS(TY_, NIT_, WR_)                                                            \
+    hipLaunchKernelGGL((k_conv_obs_sep<TY_, NIT_, WR_>), g, dim3(256), c->ob_lds, st, k, c->d_obs, \
+                       d_model, c->d_partial, c->kpad, c->nrank, c->d_obflag, c->d_obempty)
+    if (c->ob_ty == 32 && c->ob_nit == 2) { if (d_model) SLAM_OBS(32, 2, true); else SLAM_OBS(32, 2, false); }
+    else if (c->ob_ty == 32)              { if (d_model) SLAM_OBS(32, 4, true); else SLAM_OBS(32, 4, false); }
+    else                                  { if (d_model) SLAM_OBS(16, 4, true); else SLAM_OBS(16, 4, false); }
 #undef SLAM_OBS
     const int nblk = (int)(g.x * g.y) * k.nv;
     Timed t2_(c, KID_FINALIZE, st);
@@ -2105,20 +2232,24 @@ int slamhip_create(const slamhip_desc* d, slamhip_ctx** out) {
   c->red_blocks = (int)(c->rg_grid.x * c->rg_grid.y * c->rg_grid.z);
   if (d->mom0decon && c->nrank >= 1) {
     for (int ty : {32, 16}) {
-      const size_t need = ((size_t)(ty + K - 1) * ((C2_TX + K - 1) | 1) +
-                           (size_t)(ty + K - 1) * (C2_TX + 1)) * sizeof(double);
-      if (need <= 150 * 1024) { c->ob_ty = ty; c->ob_lds = need; break; }
+      const size_t rows_ = (size_t)ty + c->kpad - 1;
+      const size_t need = (rows_ * ((C2_TX + c->kpad - 1) | 1) +
+                           (c->nrank > 1 ? rows_ * (C2_TX + 1) : 0)) * sizeof(double);
+      const size_t nitem = rows_ * (C2_TX / 8);
+      if (need <= 150 * 1024 && nitem <= 1024) {
+        c->ob_ty = ty; c->ob_lds = need; c->ob_nit = (ty == 32 && nitem <= 512) ? 2 : 4;
+        break;
+      }
     }
-    if (c->ob_ty == 32) {
-      HIP_TRY(c, hipFuncSetAttribute((const void*)k_conv_obs_sep<32, true>,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->ob_lds));
-      HIP_TRY(c, hipFuncSetAttribute((const void*)k_conv_obs_sep<32, false>,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->ob_lds));
-    } else if (c->ob_ty == 16) {
-      HIP_TRY(c, hipFuncSetAttribute((const void*)k_conv_obs_sep<16, true>,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->ob_lds));
-      HIP_TRY(c, hipFuncSetAttribute((const void*)k_conv_obs_sep<16, false>,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->ob_lds));
+    if (c->ob_ty) {
+      const void* fw = c->ob_ty == 32 ? (c->ob_nit == 2 ? (const void*)k_conv_obs_sep<32, 2, true>
+                                                        : (const void*)k_conv_obs_sep<32, 4, true>)
+                                      : (const void*)k_conv_obs_sep<16, 4, true>;
+      const void* fn = c->ob_ty == 32 ? (c->ob_nit == 2 ? (const void*)k_conv_obs_sep<32, 2, false>
+                                                        : (const void*)k_conv_obs_sep<32, 4, false>)
+                                      : (const void*)k_conv_obs_sep<16, 4, false>;
+      HIP_TRY(c, hipFuncSetAttribute(fw, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->ob_lds));
+      HIP_TRY(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->ob_lds));
     }
   }
   c->ob_grid = dim3((k.nx + C2_TX - 1) / C2_TX, (k.ny + C2_TY - 1) / C2_TY, k.nv);
@@ -2162,6 +2293,25 @@ int slamhip_create(const slamhip_desc* d, slamhip_ctx** out) {
   if ((rc = dev_alloc(c, &c->d_tile_ix, W * c->fz_grid.x * 2))) return rc;
   if ((rc = dev_alloc(c, &c->d_tile_jy, W * c->fz_grid.y * 2))) return rc;
   HIP_TRY(c, hipStreamCreate(&c->stream));
+  if (d->mom0decon && c->ob_ty) {
+    // residual sum of every (channel, tile) when the model is zero there: this
+    // fit's data^2 summed by the beam kernel itself on an all-zero cube
+    c->ob_nty = (k.ny + c->ob_ty - 1) / c->ob_ty;
+    const size_t ntile = (size_t)c->ob_grid.x * c->ob_nty;
+    if ((rc = dev_alloc(c, &c->d_obflag, W * k.nv * ntile))) return rc;
+    if ((rc = dev_alloc(c, &c->d_obempty, (size_t)k.nv * ntile))) return rc;
+    HIP_TRY(c, hipMemsetAsync(c->d_obs, 0, ncube * sizeof(double), c->stream));
+    dim3 g(c->ob_grid.x, c->ob_nty, k.nv);
+#define SLAM_OBS0(TY_, NIT_)                                                                 \
+    hipLaunchKernelGGL((k_conv_obs_sep<TY_, NIT_, false>), g, dim3(256), c->ob_lds, c->stream, k, \
+                       c->d_obs, (double*)nullptr, c->d_obempty, c->kpad, c->nrank,          \
+                       (const unsigned char*)nullptr, (const double*)nullptr)
+    if (c->ob_ty == 32 && c->ob_nit == 2) SLAM_OBS0(32, 2);
+    else if (c->ob_ty == 32) SLAM_OBS0(32, 4);
+    else SLAM_OBS0(16, 4);
+#undef SLAM_OBS0
+    HIP_TRY(c, hipGetLastError());
+  }
   HIP_TRY(c, hipDeviceSynchronize());
   return SLAMHIP_OK;
 }
