@@ -810,7 +810,7 @@ __global__ void __launch_bounds__(CV_NT, 4)
 k_conv_chi2(FitK g, const double* __restrict__ iunif,
             const int* __restrict__ cellx, const double* __restrict__ fracx,
             const int* __restrict__ celly, const double* __restrict__ fracy,
-            const WinDesc* __restrict__ list, const int* __restrict__ count, int wnx, int wny,
+            const WinDesc* __restrict__ list, int* __restrict__ count, int wnx, int wny,
             double* __restrict__ partial, int kpad, int nrank) {
   extern __shared__ double lds[];
   constexpr int TX = CONV_TX, R = CONV_R, PC = TX + 1, P2 = TX + 1;
@@ -836,16 +836,27 @@ k_conv_chi2(FitK g, const double* __restrict__ iunif,
   const int nlive = *count;
   constexpr int DW = sizeof(WinDesc) / 4;                   // descriptor dwords
   __shared__ __attribute__((aligned(16))) unsigned s_desc[2][DW];
-  if (tid < DW && (int)blockIdx.x < nlive)
-    s_desc[0][tid] = reinterpret_cast<const unsigned*>(&list[blockIdx.x])[tid];
+  __shared__ int s_ticket;
+  // Windows differ in cost (rows and tiles with emission), so a workgroup takes
+  // its first window by position and every later one from a shared ticket
+  // counter (`count[1]`, zeroed with the list).  Tickets are drawn two windows
+  // ahead: one window hides the counter's round trip, the next the descriptor's.
+  int* queue = count + 1;
+  if ((int)blockIdx.x >= nlive) return;                     // whole workgroup
+  if (tid < DW) s_desc[0][tid] = reinterpret_cast<const unsigned*>(&list[blockIdx.x])[tid];
+  if (tid == 0) s_ticket = (int)gridDim.x + atomicAdd(queue, 1);
   __syncthreads();
-  // every wave reaches the loop exit after ceil(nlive / gridDim.x) iterations
+  int nxt = s_ticket;
+  // every wave reaches the loop exit: tickets only grow, and a workgroup stops
+  // drawing once it holds one past the end of the list
   int par = 0;
-  for (int it = blockIdx.x; it < nlive; it += gridDim.x, par ^= 1) {
+  for (int it = blockIdx.x; it < nlive; par ^= 1) {
     // next window's descriptor: in flight during this window, parked in LDS at its end
     unsigned nextw = 0;
-    if (tid < DW && it + (int)gridDim.x < nlive)
-      nextw = reinterpret_cast<const unsigned*>(&list[it + gridDim.x])[tid];
+    if (tid < DW && nxt < nlive)
+      nextw = reinterpret_cast<const unsigned*>(&list[nxt])[tid];
+    int fut = nlive;
+    if (tid == 0 && nxt < nlive) fut = (int)gridDim.x + atomicAdd(queue, 1);
     const WinDesc* cur = reinterpret_cast<const WinDesc*>(&s_desc[par][0]);   // in LDS
     const int e = cur->e;
     const int z = e / (wnx * wny), tl = e - z * (wnx * wny);
@@ -921,7 +932,6 @@ k_conv_chi2(FitK g, const double* __restrict__ iunif,
     }
     {
       // wave <-> rows, lanes <-> columns; only rows the row pass will read
-      const double2 zz = make_double2(0.0, 0.0);
       for (int rr = wv; rr < rows; rr += CV_NW) {
         const unsigned long long mw = rr < 64 ? m0 : rr < 128 ? m1 : rr < 192 ? m2 : m3;
         if (!((mw >> (rr & 63)) & 1ull)) continue;          // wave-uniform
@@ -930,7 +940,6 @@ k_conv_chi2(FitK g, const double* __restrict__ iunif,
           if (c2 + 1 < P) { rowp[c2] = 0.0; rowp[c2 + 1] = 0.0; } else rowp[c2] = 0.0;
         }
       }
-      (void)zz;
     }
     __syncthreads();
 
@@ -1099,6 +1108,7 @@ k_conv_chi2(FitK g, const double* __restrict__ iunif,
     ff = wave_sum(ff);
     if (lane == 0) { sg[wv] = gf; sf[wv] = ff; }
     if (tid < DW) s_desc[par ^ 1][tid] = nextw;
+    if (tid == 0) s_ticket = fut;
     __syncthreads();
     if (tid == 0) {
       double a = 0.0, b2 = 0.0;
@@ -1108,6 +1118,8 @@ k_conv_chi2(FitK g, const double* __restrict__ iunif,
       partial[3 * (long long)e + 1] = b2;
       partial[3 * (long long)e + 2] = 1.0;                  // window was convolved
     }
+    it = nxt;
+    nxt = s_ticket;
     // the next window's first barrier orders its LDS writes after these reads
   }
 }
