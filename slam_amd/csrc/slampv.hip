@@ -38,7 +38,10 @@ namespace {
 
 constexpr int ZCHUNK = 288;     // longest z run one lane walks
 constexpr int ZU = 8;           // cells in flight per lane
-constexpr int TAU_WAVES = 4;    // walkers (waves) per k_pv_tau workgroup
+constexpr int TAU_W = 8;        // walkers per k_pv_tau wave (neighbours in Rc)
+constexpr int TAU_C = 64 / TAU_W;   // columns per wave
+constexpr int TAU_WAVES = 4;    // waves per k_pv_tau workgroup
+constexpr int TASK_COLS = TAU_C * TAU_WAVES;   // columns per task
 constexpr int MAX_LEVELS = 12;
 constexpr int NT = 256;         // threads of the small kernels
 
@@ -139,24 +142,25 @@ __global__ __launch_bounds__(64 * TAU_WAVES) void k_pv_tau(PvK k, const Task* __
   const int lane = threadIdx.x & 63;
   for (int i = threadIdx.x; i <= nv; i += 64 * TAU_WAVES) s_edge[i] = k.vedge[i];
   __syncthreads();
-  // The TAU_WAVES waves of a workgroup take the same columns for TAU_WAVES
-  // walkers that are neighbours in the Rc-sorted batch: they share one CU's L1
-  // and gather neighbouring table columns, and the cell constants of a task are
-  // fetched from HBM once for all walkers (L2).  Workgroups go round-robin over
-  // the 8 XCDs, each with its own L2: XCD x takes the x-th eighth of the sorted
-  // batch.
+  // A wave is TAU_C neighbouring columns x TAU_W walkers that are neighbours
+  // in the Rc-sorted batch (adjacent lanes = adjacent walkers): for one cell
+  // their table gathers fall on the same or adjacent 64-B lines, and the cell
+  // constants are one line per array for the whole wave.  The cell constants of
+  // a task come from HBM once for all walkers (L2).  Workgroups go round-robin
+  // over the 8 XCDs, each with its own L2: XCD x takes the x-th eighth of the
+  // sorted batch.
   const Task t = tasks[blockIdx.y];
-  const int ngroup = (nw + TAU_WAVES - 1) / TAU_WAVES;
+  const int ngroup = (nw + TAU_W - 1) / TAU_W;
   const int per = (ngroup + 7) >> 3;
   const int b = blockIdx.x;
   const int grp = ngroup < 16 ? b : (b & 7) * per + (b >> 3);
-  const int slot = grp * TAU_WAVES + (threadIdx.x >> 6);
-  if (grp >= ngroup || slot >= nw) return;   // whole waves leave, after the only barrier
-  const int w = order[slot];
+  if (grp >= ngroup) return;                  // whole workgroup, after the only barrier
+  const int slot = grp * TAU_W + (lane & (TAU_W - 1));
+  const int w = order[min(slot, nw - 1)];
   const LevelK& L = k.lv[t.level];
   const WalkerPV q = wk[w];
-  const int ci = t.col0 + lane;               // index into the level's used-column list
-  const bool active = ci < L.nused;
+  const int ci = t.col0 + (threadIdx.x >> 6) * TAU_C + lane / TAU_W;   // index into the level's used-column list
+  const bool active = slot < nw && ci < L.nused;
   const int col = active ? L.used[ci] : 0;
   const int z0 = t.chunk * L.zlen;
   const int z1 = min(L.nz, z0 + L.zlen);
@@ -627,7 +631,7 @@ int run_group(slampv_ctx* c, const double* d_params, int nw, double* d_lnp, doub
   }
   {
     Timed t(c, PK_TAU, st);
-    const int ngroup = (nw + TAU_WAVES - 1) / TAU_WAVES;
+    const int ngroup = (nw + TAU_W - 1) / TAU_W;
     const int gx = ngroup < 16 ? ngroup : ((ngroup + 7) >> 3) << 3;
     hipLaunchKernelGGL(k_pv_tau, dim3(gx, c->ntask), dim3(64 * TAU_WAVES), c->lds_tau, st, k, c->d_tasks,
                        c->d_wk, c->d_order, nw, c->d_own);
@@ -775,7 +779,7 @@ int slampv_create(const slampv_desc* d, slampv_ctx** out) {
       L.own_off[a] = off;
       off += (long long)L.nchunk * d->nv * L.nused;
       for (int ch = 0; ch < L.nchunk; ++ch)
-        for (int c0 = 0; c0 < L.nused; c0 += 64) tasks.push_back({a, l, c0, ch});
+        for (int c0 = 0; c0 < L.nused; c0 += TASK_COLS) tasks.push_back({a, l, c0, ch});
     }
   }
   k.own_stride = off;
