@@ -846,7 +846,7 @@ k_conv_chi2(FitK g, const double* __restrict__ iunif,
   if (tid < DW) s_desc[0][tid] = reinterpret_cast<const unsigned*>(&list[blockIdx.x])[tid];
   if (tid == 0) s_ticket = (int)gridDim.x + atomicAdd(queue, 1);
   __syncthreads();
-  int nxt = s_ticket;
+  int nxt = __builtin_amdgcn_readfirstlane(s_ticket);     // block-uniform, kept scalar
   // every wave reaches the loop exit: tickets only grow, and a workgroup stops
   // drawing once it holds one past the end of the list
   int par = 0;
@@ -858,7 +858,7 @@ k_conv_chi2(FitK g, const double* __restrict__ iunif,
     int fut = nlive;
     if (tid == 0 && nxt < nlive) fut = (int)gridDim.x + atomicAdd(queue, 1);
     const WinDesc* cur = reinterpret_cast<const WinDesc*>(&s_desc[par][0]);   // in LDS
-    const int e = cur->e;
+    const int e = __builtin_amdgcn_readfirstlane(cur->e);   // descriptor fields are block-uniform: keep them scalar
     const int z = e / (wnx * wny), tl = e - z * (wnx * wny);
     const int tby = tl / wnx, tbx = tl - tby * wnx;
     const int wi = z / g.nv, k = z - wi * g.nv;
@@ -867,7 +867,7 @@ k_conv_chi2(FitK g, const double* __restrict__ iunif,
     const int wx0 = x0 - ng, wy0 = y0 - ng;                 // window origin (image coords)
     const int ftx0 = max(wx0, 0) / PT_X, fty0 = max(wy0, 0) / PT_Y;
     const int fnx = min(wx0 + vcols - 1, n - 1) / PT_X - ftx0 + 1;
-    const int nocc = cur->nocc;
+    const int nocc = __builtin_amdgcn_readfirstlane(cur->nocc);
 
     // -- 0. issue every global load of this window now: the occupied input
     //       tiles (NSB per wave in registers) and what the regrid needs
@@ -896,7 +896,8 @@ k_conv_chi2(FitK g, const double* __restrict__ iunif,
       }
     }
     const double* dat = g.data + (long long)k * g.ny * g.nx;
-    const int ixa = cur->ixa, ixb = cur->ixb, jya = cur->jya, jyb = cur->jyb;
+    const int ixa = __builtin_amdgcn_readfirstlane(cur->ixa), ixb = __builtin_amdgcn_readfirstlane(cur->ixb);
+    const int jya = __builtin_amdgcn_readfirstlane(cur->jya), jyb = __builtin_amdgcn_readfirstlane(cur->jyb);
     const int ix = ixa + lane;
     int i1 = -1;
     double t1 = 0.0;
@@ -1119,7 +1120,7 @@ k_conv_chi2(FitK g, const double* __restrict__ iunif,
       partial[3 * (long long)e + 2] = 1.0;                  // window was convolved
     }
     it = nxt;
-    nxt = s_ticket;
+    nxt = __builtin_amdgcn_readfirstlane(s_ticket);
     // the next window's first barrier orders its LDS writes after these reads
   }
 }

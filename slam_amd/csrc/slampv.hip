@@ -40,7 +40,7 @@ constexpr int ZCHUNK = 288;     // longest z run one lane walks
 constexpr int ZU = 8;           // cells in flight per lane
 constexpr int TAU_W = 8;        // walkers per k_pv_tau wave (neighbours in Rc)
 constexpr int TAU_C = 64 / TAU_W;   // columns per wave
-constexpr int TAU_WAVES = 4;    // waves per k_pv_tau workgroup
+constexpr int TAU_WAVES = 1;    // waves per k_pv_tau workgroup (2, 4: same speed; 8: slower)
 constexpr int TASK_COLS = TAU_C * TAU_WAVES;   // columns per task
 constexpr int MAX_LEVELS = 12;
 constexpr int NT = 256;         // threads of the small kernels
@@ -129,112 +129,135 @@ __global__ void k_pv_prep(PvK k, const double* __restrict__ params, int nw,
 }
 
 // ---------------------------------------------------------------------------
-// One wave = 64 neighbouring columns of one (axis, level, z chunk).  A lane
-// walks its column along z, keeps the running sum of the channel it is in and
-// adds it to its own column of the chunk's image when the channel changes.
+// One wave = TAU_C neighbouring columns of one (axis, level, z chunk) x TAU_W
+// walkers.  A lane walks its column along z for its walker, keeps the running
+// sum of the channel it is in and adds it to its own column of the chunk's
+// image when the channel changes.
+constexpr int STG_D = 4 * 64 + 32;   // doubles per staging buffer: jo, er, et, ep [64] + it [64] (int)
+
 __global__ __launch_bounds__(64 * TAU_WAVES) void k_pv_tau(PvK k, const Task* __restrict__ tasks,
                                                const WalkerPV* __restrict__ wk,
                                                const int* __restrict__ order, int nw,
-                                               double* __restrict__ own) {
+                                               int ntask, double* __restrict__ own) {
+  static_assert(ZU * TAU_C == 64, "one staged (cell, column) pair per lane");
   extern __shared__ double sh[];
   const int nv = k.nv;
   double* s_edge = sh;                       // [nv+1]
-  const int lane = threadIdx.x & 63;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double* stg = sh + ((nv + 2) & ~1) + wave * (2 * STG_D);   // this wave's two staging buffers
   for (int i = threadIdx.x; i <= nv; i += 64 * TAU_WAVES) s_edge[i] = k.vedge[i];
   __syncthreads();
   // A wave is TAU_C neighbouring columns x TAU_W walkers that are neighbours
   // in the Rc-sorted batch (adjacent lanes = adjacent walkers): for one cell
-  // their table gathers fall on the same or adjacent 64-B lines, and the cell
-  // constants are one line per array for the whole wave.  The cell constants of
-  // a task come from HBM once for all walkers (L2).  Workgroups go round-robin
-  // over the 8 XCDs, each with its own L2: XCD x takes the x-th eighth of the
-  // sorted batch.
-  const Task t = tasks[blockIdx.y];
+  // their table gathers fall on the same or adjacent 64-B lines.  The cell
+  // constants do not depend on the walker: each trip the 64 lanes fetch them
+  // for ZU cells x TAU_C columns, one (cell, column) pair per lane, park them in
+  // LDS and read them back per (column, walker) lane; the next trip's fetch is
+  // in flight during this trip's gathers.  The cell constants of a task come
+  // from HBM once for all walkers (L2).  Workgroups go round-robin over the 8
+  // XCDs, each with its own L2: XCD x takes the x-th eighth of the sorted batch.
+  const int ti = blockIdx.z * gridDim.y + blockIdx.y;   // grid.y alone is limited to 65535
   const int ngroup = (nw + TAU_W - 1) / TAU_W;
   const int per = (ngroup + 7) >> 3;
   const int b = blockIdx.x;
   const int grp = ngroup < 16 ? b : (b & 7) * per + (b >> 3);
-  if (grp >= ngroup) return;                  // whole workgroup, after the only barrier
+  if (grp >= ngroup || ti >= ntask) return;   // whole workgroup; every barrier below is reached by all of the others
+  const Task t = tasks[ti];
   const int slot = grp * TAU_W + (lane & (TAU_W - 1));
   const int w = order[min(slot, nw - 1)];
   const LevelK& L = k.lv[t.level];
   const WalkerPV q = wk[w];
-  const int ci = t.col0 + (threadIdx.x >> 6) * TAU_C + lane / TAU_W;   // index into the level's used-column list
+  const int mc = lane / TAU_W;                // this lane's column within the wave
+  const int ci = t.col0 + wave * TAU_C + mc;  // index into the level's used-column list
   const bool active = slot < nw && ci < L.nused;
-  const int col = active ? L.used[ci] : 0;
   const int z0 = t.chunk * L.zlen;
   const int z1 = min(L.nz, z0 + L.zlen);
   const double e0 = s_edge[0];
   const double inv_dv = (double)nv / (s_edge[nv] - e0);
-  if (active) {
-    const int* __restrict__ it = L.it[t.axis];
-    const double* __restrict__ jo = L.jo[t.axis];
-    const double* __restrict__ er = L.er[t.axis];
-    const double* __restrict__ et = L.et[t.axis];
-    const double* __restrict__ ep = L.ep[t.axis];
-    const double jmax = (double)(k.nr - 1);
-    const double nvp1 = (double)nv + 1.0;
-    // the lane's own column of this chunk's image: cleared, then updated in
-    // place whenever the running channel changes (same lane, program order)
-    double* __restrict__ o = own + (size_t)w * k.own_stride + L.own_off[t.axis]
-        + (size_t)t.chunk * nv * L.nused + ci;
+  const int* __restrict__ it = L.it[t.axis];
+  const double* __restrict__ jo = L.jo[t.axis];
+  const double* __restrict__ er = L.er[t.axis];
+  const double* __restrict__ et = L.et[t.axis];
+  const double* __restrict__ ep = L.ep[t.axis];
+  const double jmax = (double)(k.nr - 1);
+  const double nvp1 = (double)nv + 1.0;
+  // fetch role: cell lu of the trip, column lc of the wave
+  const int lu = lane / TAU_C, lc = lane % TAU_C;
+  const int lci = t.col0 + wave * TAU_C + lc;
+  const int lcol = lci < L.nused ? L.used[lci] : -1;
+  int fi;
+  double fj, fr, ft, fp;
+  auto fetch = [&](int z) {
+    const int zz = z + lu;
+    const bool ok = lcol >= 0 && zz < z1;
+    const size_t c = ok ? (size_t)zz * L.ncol + lcol : 0;
+    fi = ok ? it[c] : -1;
+    fj = ok ? jo[c] : 0.0;
+    fr = ok ? er[c] : 0.0;
+    ft = ok ? et[c] : 0.0;
+    fp = ok ? ep[c] : 0.0;
+  };
+  // the lane's own column of this chunk's image: cleared, then updated in
+  // place whenever the running channel changes (same lane, program order)
+  double* __restrict__ o = own + (size_t)w * k.own_stride + L.own_off[t.axis]
+      + (size_t)t.chunk * nv * L.nused + ci;
+  fetch(z0);
+  if (active)
     for (int v = 0; v < nv; ++v) o[(size_t)v * L.nused] = 0.0;
-    int cur = -1;
-    double acc = 0.0;
-    // ZU cells per trip: their constants and table lines are requested
-    // together so that the dependent gathers overlap
-    for (int z = z0; z < z1; z += ZU) {
-      int ci[ZU];
-      double cj[ZU], cr[ZU], ct[ZU], cp[ZU];
+  int cur = -1;
+  double acc = 0.0;
+  int buf = 0;
+  for (int z = z0; z < z1; z += ZU, buf ^= 1) {
+    double* B = stg + buf * STG_D;
+    int* Bi = reinterpret_cast<int*>(B + 4 * 64);
+    B[lane] = fj; B[64 + lane] = fr; B[128 + lane] = ft; B[192 + lane] = fp;
+    Bi[lane] = fi;
+    __syncthreads();            // staging is per wave; this orders its LDS writes and reads
+    if (z + ZU < z1) fetch(z + ZU);
+    // ZU cells per trip: their table lines are requested together so that the
+    // dependent gathers overlap
+    int ci_[ZU];
+    double2 ta[ZU], tb[ZU];
+    double tv[ZU];
 #pragma unroll
-      for (int u = 0; u < ZU; ++u) {
-        const int zz = min(z + u, z1 - 1);
-        const size_t c = (size_t)zz * L.ncol + col;
-        ci[u] = (z + u < z1) ? it[c] : -1;
-        cj[u] = jo[c];
-        cr[u] = er[c];
-        ct[u] = et[c];
-        cp[u] = ep[c];
-      }
-      double2 ta[ZU], tb[ZU];
-      double tv[ZU];
+    for (int u = 0; u < ZU; ++u) {
+      const int se = u * TAU_C + mc;
+      ci_[u] = active ? Bi[se] : -1;
+      double j = B[se] - q.shift;
+      j = fmin(fmax(j, 0.0), jmax);           // NaN -> 0; the prior lets no such Rc through
+      const double* e = k.table + ((size_t)max(ci_[u], 0) * k.nr + (int)j) * 8;
+      ta[u] = *reinterpret_cast<const double2*>(e);       // rho_env, rho_disk
+      tb[u] = *reinterpret_cast<const double2*>(e + 2);   // vr_env, vt_env
+      tv[u] = e[4];                                       // vp_env + vp_disk
+    }
 #pragma unroll
-      for (int u = 0; u < ZU; ++u) {
-        double j = cj[u] - q.shift;
-        j = fmin(fmax(j, 0.0), jmax);           // NaN -> 0; the prior lets no such Rc through
-        const double* e = k.table + ((size_t)max(ci[u], 0) * k.nr + (int)j) * 8;
-        ta[u] = *reinterpret_cast<const double2*>(e);       // rho_env, rho_disk
-        tb[u] = *reinterpret_cast<const double2*>(e + 2);   // vr_env, vt_env
-        tv[u] = e[4];                                       // vp_env + vp_disk
-      }
-#pragma unroll
-      for (int u = 0; u < ZU; ++u) {
-        if (ci[u] < 0) continue;
-        const double rho = ta[u].x + ta[u].y * q.frho;
-        if (rho == 0.0) continue;               // adds nothing to any channel
-        const double vr = tb[u].x * q.alpha;
-        double vl = vr * cr[u] + tb[u].y * ct[u];
-        vl = vl + tv[u] * cp[u];
-        vl = vl * q.vunit;
-        // channel: vedge[b] <= vl < vedge[b+1], decided on the stored edges
-        const double fb = (vl - e0) * inv_dv;
-        if (!(fb >= -1.0 && fb <= nvp1)) continue;          // also NaN
-        int bn = (int)floor(fb);
-        bn = min(max(bn, 0), nv - 1);
-        while (bn > 0 && vl < s_edge[bn]) --bn;
-        while (bn < nv - 1 && vl >= s_edge[bn + 1]) ++bn;
-        if (!(s_edge[bn] <= vl && vl < s_edge[bn + 1])) continue;   // outside every channel
-        if (bn != cur) {
-          if (cur >= 0) o[(size_t)cur * L.nused] += acc;
-          cur = bn;
-          acc = rho;
-        } else {
-          acc += rho;
-        }
+    for (int u = 0; u < ZU; ++u) {
+      if (ci_[u] < 0) continue;
+      const double rho = ta[u].x + ta[u].y * q.frho;
+      if (rho == 0.0) continue;               // adds nothing to any channel
+      const double vr = tb[u].x * q.alpha;
+      const int e = u * TAU_C + mc;           // line-of-sight projections, from the staging buffer
+      double vl = vr * B[64 + e] + tb[u].y * B[128 + e];
+      vl = vl + tv[u] * B[192 + e];
+      vl = vl * q.vunit;
+      // channel: vedge[b] <= vl < vedge[b+1], decided on the stored edges
+      const double fb = (vl - e0) * inv_dv;
+      if (!(fb >= -1.0 && fb <= nvp1)) continue;          // also NaN
+      int bn = (int)floor(fb);
+      bn = min(max(bn, 0), nv - 1);
+      while (bn > 0 && vl < s_edge[bn]) --bn;
+      while (bn < nv - 1 && vl >= s_edge[bn + 1]) ++bn;
+      if (!(s_edge[bn] <= vl && vl < s_edge[bn + 1])) continue;   // outside every channel
+      if (bn != cur) {
+        if (cur >= 0) o[(size_t)cur * L.nused] += acc;
+        cur = bn;
+        acc = rho;
+      } else {
+        acc += rho;
       }
     }
-    if (cur >= 0) o[(size_t)cur * L.nused] += acc;
   }
+  if (cur >= 0) o[(size_t)cur * L.nused] += acc;
 }
 
 // ---------------------------------------------------------------------------
@@ -633,8 +656,9 @@ int run_group(slampv_ctx* c, const double* d_params, int nw, double* d_lnp, doub
     Timed t(c, PK_TAU, st);
     const int ngroup = (nw + TAU_W - 1) / TAU_W;
     const int gx = ngroup < 16 ? ngroup : ((ngroup + 7) >> 3) << 3;
-    hipLaunchKernelGGL(k_pv_tau, dim3(gx, c->ntask), dim3(64 * TAU_WAVES), c->lds_tau, st, k, c->d_tasks,
-                       c->d_wk, c->d_order, nw, c->d_own);
+    const int gz = (c->ntask + 65534) / 65535, gy = (c->ntask + gz - 1) / gz;
+    hipLaunchKernelGGL(k_pv_tau, dim3(gx, gy, gz), dim3(64 * TAU_WAVES), c->lds_tau, st, k, c->d_tasks,
+                       c->d_wk, c->d_order, nw, c->ntask, c->d_own);
   }
   {
     Timed t(c, PK_NEST, st);
@@ -784,15 +808,13 @@ int slampv_create(const slampv_desc* d, slampv_ctx** out) {
   }
   k.own_stride = off;
   c->ntask = (int)tasks.size();
-  if (c->ntask > 65535)
-    return fail(c, SLAMPV_ERR_ARG, "%d column tasks per walker exceed the grid limit", c->ntask);
   {
     const Task* dt = nullptr;
     if ((rc = dev_upload(c, &dt, tasks.data(), tasks.size()))) return rc;
     c->d_tasks = const_cast<Task*>(dt);
   }
   // LDS budgets
-  c->lds_tau = (size_t)(d->nv + 2) * sizeof(double);
+  c->lds_tau = (size_t)(((d->nv + 2) & ~1) + TAU_WAVES * 2 * STG_D) * sizeof(double);
   c->lds_nest = (size_t)2 * k.maxpix * sizeof(double);
   c->lds_cut = ((size_t)k.npix0 * (k.has_beam ? 2 : 1) + NT + k.nx0) * sizeof(double);
   const size_t lds_cap = 150 * 1024;
