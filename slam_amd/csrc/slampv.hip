@@ -44,6 +44,8 @@ constexpr int TAU_WAVES = 1;    // waves per k_pv_tau workgroup (2, 4: same spee
 constexpr int TASK_COLS = TAU_C * TAU_WAVES;   // columns per task
 constexpr int MAX_LEVELS = 12;
 constexpr int NT = 256;         // threads of the small kernels
+constexpr int CUT_R = 5;        // outputs per k_pv_cut work item
+constexpr int CUT_PRE = 8;      // pixels per thread k_pv_cut fetches one channel ahead
 
 struct LevelK {
   int nx, ny, nz, ncol;
@@ -360,59 +362,97 @@ __global__ __launch_bounds__(NT) void k_pv_spec(PvK k, const double* __restrict_
 }
 
 // ---------------------------------------------------------------------------
-// One block per (channel, axis, walker): intensity, centre row of the beam
-// convolution, sub-grid mean, flip, and the three sums the flux scale needs.
+// One block per (channel subset, axis, walker): intensity, centre row of the
+// beam convolution, sub-grid mean, flip, and the three sums the flux scale
+// needs.  The block keeps the padded beam in LDS and walks its channels
+// (blockIdx.x, + gridDim.x, ...), the next channel's optical depths being
+// fetched while the current one is convolved.
 __global__ __launch_bounds__(NT) void k_pv_cut(PvK k, const WalkerPV* __restrict__ wk,
                                                const double* __restrict__ tau0,
                                                const unsigned long long* __restrict__ tmaxbits,
                                                double* __restrict__ pv,
                                                double* __restrict__ part) {
   extern __shared__ double sh[];
+  constexpr int R = CUT_R;
+  const int ngx = (k.nx0 + R - 1) / R;     // groups of R neighbouring outputs
+  const int GP = ngx * R + k.nx0 + R;      // padded beam row: tap gi lives at gi + padl, zeros around
   double* s_I = sh;                        // [npix0]
-  double* s_g = s_I + k.npix0;             // [npix0] (beam) or unused
-  double* s_part = s_g + (k.has_beam ? k.npix0 : 0);   // [P][nx0]
-  double* s_row = s_part + (size_t)NT;     // [nx0] fine PV row
+  double* s_g = s_I + k.npix0;             // [ny0][GP] (beam) or unused
+  double* s_part = s_g + (k.has_beam ? (size_t)k.ny0 * GP : 0);   // [ny0][ngx*R]
+  double* s_row = s_part + (k.has_beam ? (size_t)k.ny0 * ngx * R : 0);     // [nx0] fine PV row
   __shared__ double s_red[3][NT / 64];
-  const int v = blockIdx.x, ax = blockIdx.y, w = blockIdx.z;
+  const int ax = blockIdx.y, w = blockIdx.z;
   const int tid = threadIdx.x;
   const int nx0 = k.nx0, ny0 = k.ny0;
   const double mx = __longlong_as_double((long long)tmaxbits[2 * w + ax]);
   const double tm = wk[w].taumax;
-  const double* t = tau0 + (((size_t)w * 2 + ax) * k.nv + v) * k.npix0;
-  for (int p = tid; p < k.npix0; p += NT) {
-    s_I[p] = 1. - exp(-t[p] / mx * tm);                           // mockpvd.py:316
-    if (k.has_beam) s_g[p] = k.gauss_xy[p];
-  }
-  __syncthreads();
-  const int yc = ny0 / 2;
+  const double* tw = tau0 + ((size_t)w * 2 + ax) * k.nv * k.npix0;
+  double pre[CUT_PRE];                     // this thread's pixels of the channel to come
+  auto prefetch = [&](int v) {
+    const double* t = tw + (size_t)v * k.npix0;
+#pragma unroll
+    for (int i = 0; i < CUT_PRE; ++i) {
+      const int p = tid + i * NT;
+      pre[i] = p < k.npix0 ? t[p] : 0.0;
+    }
+  };
+  prefetch(blockIdx.x);
+  const int cy = (ny0 - 1) / 2, cx = (nx0 - 1) / 2;
+  const int padl = nx0 - 1 - cx + R;
   if (k.has_beam) {
-    // scipy 'same': out[yc][x] = sum I[y'][x'] g[yc+cy-y'][x+cx-x']
-    const int cy = (ny0 - 1) / 2, cx = (nx0 - 1) / 2;
-    const int P = nx0 >= NT ? 1 : NT / nx0;     // row groups working on one x
-    for (int x0 = 0; x0 < nx0; x0 += NT) {
-      const int x = x0 + (P == 1 ? tid : tid % nx0);
-      const int part_id = P == 1 ? 0 : tid / nx0;
-      if (x < nx0 && part_id < P) {
-        double s = 0.0;
-        for (int yp = part_id; yp < ny0; yp += P) {
-          const int gy = yc + cy - yp;
-          if (gy < 0 || gy >= ny0) continue;
-          const double* Ir = s_I + (size_t)yp * nx0;
-          const double* gr = s_g + (size_t)gy * nx0;
-          const int lo = max(0, x + cx - (nx0 - 1)), hi = min(nx0 - 1, x + cx);
-          for (int xp = lo; xp <= hi; ++xp) s += Ir[xp] * gr[x + cx - xp];
+    for (int e = tid; e < ny0 * GP; e += NT) {
+      const int gy = e / GP, gi = e - gy * GP - padl;
+      s_g[e] = (gi >= 0 && gi < nx0) ? k.gauss_xy[(size_t)gy * nx0 + gi] : 0.0;
+    }
+  }
+  const int yc = ny0 / 2;
+  for (int v = blockIdx.x; v < k.nv; v += gridDim.x) {
+  const double* t = tw + (size_t)v * k.npix0;
+#pragma unroll
+  for (int i = 0; i < CUT_PRE; ++i) {
+    const int p = tid + i * NT;
+    if (p < k.npix0) s_I[p] = 1. - exp(-pre[i] / mx * tm);        // mockpvd.py:316
+  }
+  for (int p = tid + CUT_PRE * NT; p < k.npix0; p += NT)
+    s_I[p] = 1. - exp(-t[p] / mx * tm);
+  __syncthreads();              // also: the beam is in place (first trip)
+  if (v + (int)gridDim.x < k.nv) prefetch(v + gridDim.x);
+  if (k.has_beam) {
+    // scipy 'same', centre row only: out[yc][x] = sum I[y'][x'] g[yc+cy-y'][x+cx-x'].
+    // An item is one input row y' for R neighbouring outputs x: I[y'][x'] is read
+    // once per x' for all R, the beam row slides through a register window
+    // (1 + 1 LDS reads per R multiply-adds); the rows are then summed in order.
+    for (int item = tid; item < ngx * ny0; item += NT) {
+      const int yp = item / ngx, xg = item - yp * ngx;
+      const int gy = yc + cy - yp;
+      double acc[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) acc[r] = 0.0;
+      if (gy >= 0 && gy < ny0) {
+        const double* Ir = s_I + (size_t)yp * nx0;
+        const double* G = s_g + (size_t)gy * GP + xg * R + cx + padl;   // G[r - x'] = g[gy][x + cx - x'], x = xg*R + r
+        double win[R];
+#pragma unroll
+        for (int r = 1; r < R; ++r) win[r] = G[r];
+        for (int xp0 = 0; xp0 < nx0; xp0 += R) {
+#pragma unroll
+          for (int q = 0; q < R; ++q) {
+            const int xp = xp0 + q;
+            const double Iv = xp < nx0 ? Ir[xp] : 0.0;
+            win[(R - q) % R] = G[-xp];
+#pragma unroll
+            for (int r = 0; r < R; ++r) acc[r] = fma(Iv, win[(r + R - q) % R], acc[r]);
+          }
         }
-        if (P == 1) s_row[x] = s;
-        else s_part[part_id * nx0 + x] = s;
       }
-      if (P > 1) {
-        __syncthreads();
-        if (tid < nx0) {
-          double s = 0.0;
-          for (int q = 0; q < P; ++q) s += s_part[q * nx0 + tid];
-          s_row[tid] = s;
-        }
-      }
+#pragma unroll
+      for (int r = 0; r < R; ++r) s_part[(size_t)yp * ngx * R + xg * R + r] = acc[r];
+    }
+    __syncthreads();
+    for (int x = tid; x < nx0; x += NT) {
+      double sum = 0.0;
+      for (int yp = 0; yp < ny0; ++yp) sum += s_part[(size_t)yp * ngx * R + x];
+      s_row[x] = sum;
     }
   } else {
     for (int x = tid; x < nx0; x += NT) s_row[x] = s_I[(size_t)yc * nx0 + x];
@@ -449,6 +489,8 @@ __global__ __launch_bounds__(NT) void k_pv_cut(PvK k, const WalkerPV* __restrict
     for (int i = 1; i < NT / 64; ++i) { A += s_red[0][i]; B += s_red[1][i]; C += s_red[2][i]; }
     double* o = part + ((((size_t)w * 2 + ax) * k.nv) + v) * 3;
     o[0] = A; o[1] = B; o[2] = C;
+  }
+  __syncthreads();              // s_I, s_row, s_red are rewritten by the next channel
   }
 }
 
@@ -674,7 +716,9 @@ int run_group(slampv_ctx* c, const double* d_params, int nw, double* d_lnp, doub
   }
   {
     Timed t(c, PK_CUT, st);
-    hipLaunchKernelGGL(k_pv_cut, dim3(k.nv, 2, nw), dim3(NT), c->lds_cut, st, k, c->d_wk, tau,
+    // enough workgroups to fill the GPU; beyond that, more channels per workgroup
+    const int split = std::min(k.nv, std::max(1, 2048 / (2 * nw)));
+    hipLaunchKernelGGL(k_pv_cut, dim3(split, 2, nw), dim3(NT), c->lds_cut, st, k, c->d_wk, tau,
                        c->d_tmax, c->d_pv, c->d_part);
   }
   {
@@ -816,7 +860,10 @@ int slampv_create(const slampv_desc* d, slampv_ctx** out) {
   // LDS budgets
   c->lds_tau = (size_t)(((d->nv + 2) & ~1) + TAU_WAVES * 2 * STG_D) * sizeof(double);
   c->lds_nest = (size_t)2 * k.maxpix * sizeof(double);
-  c->lds_cut = ((size_t)k.npix0 * (k.has_beam ? 2 : 1) + NT + k.nx0) * sizeof(double);
+  {
+    const size_t ngx = (k.nx0 + CUT_R - 1) / CUT_R, gp = ngx * CUT_R + k.nx0 + CUT_R;
+    c->lds_cut = ((size_t)k.npix0 + (k.has_beam ? (size_t)k.ny0 * (gp + ngx * CUT_R) : 0) + k.nx0) * sizeof(double);
+  }
   const size_t lds_cap = 150 * 1024;
   if (c->lds_tau > lds_cap)
     return fail(c, SLAMPV_ERR_ARG, "nv=%d needs %zu B of LDS per wave (> %zu)", d->nv, c->lds_tau, lds_cap);
