@@ -281,6 +281,8 @@ __device__ inline double surface_vlos(const FitK& g, const WalkerK& w, int s,
     vr = -rmh * sqrt(2.0 - w.Rc / r);                      // :439
   }
   const double erot = Y * g.signmajor / r;                 // :440
+  if (!(g.envelope && outer))                              // vr = 0: vr*erad adds (+-)0 for the finite r > 0 that get here
+    return (vp * erot + vr) * w.sini * g.vunit;
   const double erad = x * g.signminor / r;                 // :441
   return (vp * erot + vr * erad) * w.sini * g.vunit;       // :442
 }
@@ -319,8 +321,21 @@ k_surface(FitK g, const WalkerK* __restrict__ wk, double2* __restrict__ geom) {
   const double X = X0 * w.cp - Y0 * w.sp;                  // utils.py:355
   const double Y = X0 * w.sp + Y0 * w.cp;                  // utils.py:356
   const double lw = 1.0 / (double)(1 << (2 * l));          // avefour nesting :469-471
+  double pXc = 0.0, pb = 0.0, prt = 0.0;                   // root '+' leaves these for root '-' (same h)
   for (int s = 0; s < w.nsurf; ++s) {
-    const double xs = surface_x(w, s, X, Y);
+    double xs;
+    if (w.kind[s] == 3) {                                  // :392-405, as surface_x
+      pXc = X * w.cosi;
+      pb = (1.0 + w.h2[s]) * pXc;
+      const double c = w.qk[s] * (pXc * pXc) - w.h2[s] * (Y * Y);
+      const double D = pb * pb - w.qa[s] * c;
+      prt = D >= 0 ? sqrt(D) : __builtin_nan("");
+      xs = pXc + (pb + prt) / w.qa[s];
+    } else if (w.kind[s] == 4) {                           // :408, always right after its root '+'
+      xs = pXc + (pb - prt) / w.qa[s];
+    } else {
+      xs = surface_x(w, s, X, Y);
+    }
     const double r = sqrt(fma(xs, xs, Y * Y));             // :433
     if (surface_masked(g, w, r)) {                         // NaN vlos: most of the sky, skip the rest
       geom[((long long)wi * 4 + s) * g.nslot + leaf] = make_double2(VL_MASKED, 0.0);
