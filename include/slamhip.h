@@ -131,12 +131,15 @@ int slamhip_info(slamhip_ctx* ctx, int64_t* nleaf, int32_t* walkers_per_group,
                  int32_t* separable_beam);
 
 /* Number of outer-product terms the fused convolution uses for the beam: 1 for
- * an axis-aligned Gaussian, the leading singular triplets (tail < 1e-13) for a
- * rotated one, 0 when the hot path falls back to direct K x K taps. */
+ * an axis-aligned Gaussian; 0 = direct K x K taps, which is what a rotated
+ * Gaussian gets (its factorisation, singular triplets down to a 1e-13 tail,
+ * takes ~14 terms: more arithmetic than the taps themselves). */
 int slamhip_beam_rank(slamhip_ctx* ctx);
 
-/* Selects the convolution kernel: 0 = auto (fused separable / rank-R
- * kernel when available), 1 = force the dense direct 2-D path. */
+/* Selects the convolution kernel: 0 = auto (fused kernel; factorised beam or
+ * direct taps, see slamhip_beam_rank), 1 = force the dense, non-fused direct
+ * 2-D path, 2 = fused kernel with the factorised beam even where 0 would take
+ * direct taps (cross-checks). */
 int slamhip_set_conv_mode(slamhip_ctx* ctx, int mode);
 
 /* Measurement aid (no counterpart in the reference): between _begin and _end

@@ -44,6 +44,7 @@ constexpr int IDX_UNITS = 4;          // fast-index guard, in units of 2^-20
 constexpr double IDX_BIAS = 22.5 * 1048576.0 + IDX_UNITS + 6755399441055744.0;   // 22.5*2^20 + guard + 1.5*2^52
 constexpr int MAX_RANK = 24;                 // beam outer-product terms the fused kernel accepts
 constexpr unsigned LEAF_PAD = 0xffffffffu;    // slot without a sample
+constexpr int DIRECT_MIN_RANK = 6;           // beams needing this many terms or more get direct taps in the fused kernel
 constexpr int FLAG_MAX = 512;                // occupancy bytes one conv window may span
 
 // ---------------------------------------------------------------------------
@@ -74,6 +75,7 @@ struct FitK {
   const double* mom0decon;  // [ny][nx] deconvolved moment 0, or null (scaling='uniform')
   const double* gx_pad;     // separable factors, flipped + zero padded
   const double* gy_pad;
+  const double* beam_ft;    // [K][kpad] direct taps for the fused kernel: beam_ft[b][a] = beam[K-1-a][K-1-b], zero padded
   const unsigned* leaf;     // [nslot] packed (layer:4 | row:14 | col:14), LEAF_PAD = none
   const int* tile_goff;     // [tiles] first slot of each 32x8 pixel tile
   const int* tile_nl;       // [tiles] sample ranks in the tile (max samples per pixel)
@@ -820,15 +822,19 @@ k_compact(FitK g, const unsigned char* __restrict__ winflag, int total,
 constexpr int CV_NT = 512;                   // threads per workgroup
 constexpr int CV_NW = CV_NT / 64;            // waves
 
-template <int TY, int MAXR>
+template <int TY, int MAXR, bool DIRECT>
 __global__ void __launch_bounds__(CV_NT, 4)
 k_conv_chi2(FitK g, const double* __restrict__ iunif,
             const int* __restrict__ cellx, const double* __restrict__ fracx,
             const int* __restrict__ celly, const double* __restrict__ fracy,
             const WinDesc* __restrict__ list, int* __restrict__ count, int wnx, int wny,
             double* __restrict__ partial, int kpad, int nrank) {
+  // DIRECT (nrank == 0): the beam is not worth factorising (a rotated Gaussian
+  // needs ~14 terms): direct K x K taps on the staged tile instead of row +
+  // column passes
   extern __shared__ double lds[];
   constexpr int TX = CONV_TX, R = CONV_R, PC = TX + 1, P2 = TX + 1;
+  constexpr bool direct = DIRECT;
   constexpr int NRQ = (TY - 1 + CV_NW - 1) / CV_NW;         // regrid rows per wave
   constexpr int NSB = 2;                                    // staged tiles per wave held in registers
   __shared__ unsigned char s_rowlist[256];
@@ -843,10 +849,13 @@ k_conv_chi2(FitK g, const double* __restrict__ iunif,
   // Gaussian, the leading singular triplets for a rotated one).  With one term
   // the row-pass output overlays the input tile; with several the tile must
   // survive, so the intermediate gets LDS of its own.
-  double* wxl = lds + rows * P;                             // [nrank][kpad] flipped taps, zero padded
+  // taps sit after the tile; DIRECT also parks two TY x PC half sums in the tile's place
+  double* wxl = lds + (DIRECT ? max(rows * P, 2 * TY * PC) : rows * P);   // [nrank][kpad] flipped taps, zero padded
   double* wyl = wxl + nrank * kpad;
   double* tmp = nrank == 1 ? lds : wyl + nrank * kpad;      // [rows][P2]
   for (int e = tid; e < nrank * kpad; e += CV_NT) { wxl[e] = g.gx_pad[e]; wyl[e] = g.gy_pad[e]; }
+  if (direct)                                               // [K][kpad] taps, after the tile
+    for (int e = tid; e < K * kpad; e += CV_NT) wxl[e] = g.beam_ft[e];
   __syncthreads();
   const int nlive = *count;
   constexpr int DW = sizeof(WinDesc) / 4;                   // descriptor dwords
@@ -918,23 +927,31 @@ k_conv_chi2(FitK g, const double* __restrict__ iunif,
     double t1 = 0.0;
     double dv[NRQ], t0q[NRQ];
     int i0q[NRQ];
-    if (ix < ixb) {
-      i1 = cellx[(long long)wi * g.nx + ix] - x0;
-      t1 = fracx[(long long)wi * g.nx + ix];
-    }
+    auto regrid_loads = [&]() {
+      if (ix < ixb) {
+        i1 = cellx[(long long)wi * g.nx + ix] - x0;
+        t1 = fracx[(long long)wi * g.nx + ix];
+      }
 #pragma unroll
-    for (int q = 0; q < NRQ; ++q) {
-      const int jy = jya + wv + CV_NW * q;
-      const bool rowin = jy < jyb;
-      i0q[q] = rowin ? celly[(long long)wi * g.ny + jy] - y0 : -1;   // wave-uniform
-      t0q[q] = rowin ? fracy[(long long)wi * g.ny + jy] : 0.0;
-      dv[q] = (ix < ixb && rowin) ? dat[(long long)jy * g.nx + ix] : 0.0;
-    }
-    const bool xown = i1 >= 0 && i1 < TX - 1;               // else owned by another window
+      for (int q = 0; q < NRQ; ++q) {
+        const int jy = jya + wv + CV_NW * q;
+        const bool rowin = jy < jyb;
+        i0q[q] = rowin ? celly[(long long)wi * g.ny + jy] - y0 : -1;   // wave-uniform
+        t0q[q] = rowin ? fracy[(long long)wi * g.ny + jy] : 0.0;
+        dv[q] = (ix < ixb && rowin) ? dat[(long long)jy * g.nx + ix] : 0.0;
+      }
+    };
+    // the direct taps need the registers: there the loads wait until the taps are done
+    if (!DIRECT) regrid_loads();
 
     // -- 1. rows that hold emission; zero them in the LDS tile
-    const unsigned long long m0 = cur->rowmask[0], m1 = cur->rowmask[1],
-                             m2 = cur->rowmask[2], m3 = cur->rowmask[3];
+    auto uniform64 = [](unsigned long long v) {             // block-uniform value into SGPRs
+      const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+      const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+      return ((unsigned long long)hi << 32) | lo;
+    };
+    const unsigned long long m0 = uniform64(cur->rowmask[0]), m1 = uniform64(cur->rowmask[1]),
+                             m2 = uniform64(cur->rowmask[2]), m3 = uniform64(cur->rowmask[3]);
     const int nlr = __popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3);
     if (tid < rows) {
       const unsigned long long mw = tid < 64 ? m0 : tid < 128 ? m1 : tid < 192 ? m2 : m3;
@@ -950,7 +967,7 @@ k_conv_chi2(FitK g, const double* __restrict__ iunif,
       // wave <-> rows, lanes <-> columns; only rows the row pass will read
       for (int rr = wv; rr < rows; rr += CV_NW) {
         const unsigned long long mw = rr < 64 ? m0 : rr < 128 ? m1 : rr < 192 ? m2 : m3;
-        if (!((mw >> (rr & 63)) & 1ull)) continue;          // wave-uniform
+        if (!direct && !((mw >> (rr & 63)) & 1ull)) continue;   // wave-uniform; direct taps read every row
         double* rowp = lds + rr * P;
         for (int c2 = lane * 2; c2 < P; c2 += 128) {
           if (c2 + 1 < P) { rowp[c2] = 0.0; rowp[c2 + 1] = 0.0; } else rowp[c2] = 0.0;
@@ -1003,7 +1020,44 @@ k_conv_chi2(FitK g, const double* __restrict__ iunif,
     double acc[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) acc[r] = 0.0;
-    for (int rk = 0; rk < nrank; ++rk) {
+    // direct taps: wave <-> (block of RB output rows, half of the tap columns);
+    // the two halves are added through LDS afterwards
+    constexpr int RB = TY == 64 ? 2 * R : R;
+    static_assert(TY / RB == CV_NW / 2, "four row blocks, two tap-column halves");
+    const int rb = wv % (TY / RB), tapset = wv / (TY / RB);
+    double dacc[DIRECT ? RB : 1];
+    if (DIRECT) {
+#pragma unroll
+      for (int r = 0; r < RB; ++r) dacc[r] = 0.0;
+      // out[y][x] = sum_{a,b} beam[K-1-a][K-1-b] tile[y+a][x+b]: per tap column b a
+      // sliding pass along y (lanes <-> x; RB+R-1 tile reads and R tap reads per
+      // RB*R multiply-adds); tap blocks over rows without emission are skipped
+      for (int b = tapset; b < K; b += 2) {
+        const double* wb = wxl + b * kpad;                  // LDS, same address in every lane
+        const double* col = lds + (rb * RB) * P + lane + b;
+        for (int u0 = 0; u0 < kpad; u0 += R) {
+          const int ra = rb * RB + u0;
+          unsigned long long bits = 0ull;
+          {
+            const int w0 = ra >> 6, sh = ra & 63;
+            const unsigned long long lo = w0 == 0 ? m0 : w0 == 1 ? m1 : w0 == 2 ? m2 : m3;
+            const unsigned long long hi = w0 == 0 ? m1 : w0 == 1 ? m2 : w0 == 2 ? m3 : 0ull;
+            bits = (lo >> sh) | (sh ? (hi << (64 - sh)) : 0ull);
+          }
+          if (!(bits & ((1ull << (RB + R - 1)) - 1ull))) continue;
+          double win[RB + R - 1];
+#pragma unroll
+          for (int r = 0; r < RB + R - 1; ++r) win[r] = col[(u0 + r) * P];
+#pragma unroll
+          for (int qq = 0; qq < R; ++qq) {
+            const double wgt = wb[u0 + qq];
+#pragma unroll
+            for (int r = 0; r < RB; ++r) dacc[r] = fma(wgt, win[r + qq], dacc[r]);
+          }
+        }
+      }
+    }
+    for (int rk = 0; !DIRECT && rk < nrank; ++rk) {
       const double* wxr = wxl + rk * kpad;
       const double* wyr = wyl + rk * kpad;
       double res[MAXR][R];
@@ -1079,8 +1133,22 @@ k_conv_chi2(FitK g, const double* __restrict__ iunif,
         }
       }
     }
+    if (DIRECT) regrid_loads();
+    const bool xown = i1 >= 0 && i1 < TX - 1;               // else owned by another window
     __syncthreads();                                        // column pass done reading LDS
-    if (wv < TY / R) {
+    if (DIRECT) {
+      double* half = lds + TY * PC;                         // the odd tap columns' sums
+      if (tapset == 1) {
+#pragma unroll
+        for (int r = 0; r < RB; ++r) half[(rb * RB + r) * PC + lane] = dacc[r];
+      }
+      __syncthreads();
+      if (tapset == 0) {
+#pragma unroll
+        for (int r = 0; r < RB; ++r)
+          lds[(rb * RB + r) * PC + lane] = dacc[r] + half[(rb * RB + r) * PC + lane];
+      }
+    } else if (wv < TY / R) {
 #pragma unroll
       for (int r = 0; r < R; ++r) lds[(wv * R + r) * PC + lane] = acc[r];
     }
@@ -1684,7 +1752,10 @@ struct slamhip_ctx {
   int conv_mode = 0;
   int kpad = 0;
   int sep_variant = 0;     // 0: <64,3>  1: <64,5>  2: <32,4>  -1: none fits
-  int nrank = 1;           // outer-product terms of the beam used by the fused kernel
+  int nrank = 1;           // outer-product terms of the factorised beam (0: not factorised)
+  int fz_rank = 1;         // what the fused kernel uses in conv mode 0: nrank, or 0 = direct taps
+  size_t fz_lds_direct = 0;
+  int persist_direct = 1;
   size_t sep_lds = 0, c2d_lds = 0, fz_lds = 0;
   hipStream_t stream = nullptr;
   // optional per-kernel HIP-event timing (slamhip_profile_begin/_end)
@@ -1856,7 +1927,7 @@ size_t sep_lds_bytes(int TY, int kpad) {
 int run_conv(slamhip_ctx* c, const double* in, double* out, int planes,
              hipStream_t st) {
   const int n = c->k.nneed;
-  const bool sep = c->separable && c->conv_mode == 0 && c->sep_variant >= 0;
+  const bool sep = c->separable && c->conv_mode != 1 && c->sep_variant >= 0;
   // grid.z is limited to 65535 planes per launch
   for (int p0 = 0; p0 < planes; p0 += 32768) {
     const int np_ = std::min(32768, planes - p0);
@@ -1930,7 +2001,7 @@ int run_group_mom0(slamhip_ctx* c, const double* d_params, int nw, double* d_chi
   {
     Timed t_(c, KID_REGRID, st);
     const long long npix = (long long)k.ny * k.nx;
-    const bool flagged = c->ob_ty && c->conv_mode == 0 && convolving;
+    const bool flagged = c->ob_ty && c->conv_mode != 1 && convolving;
     if (flagged)
       HIP_TRY(c, hipMemsetAsync(c->d_obflag, 0, (size_t)nw * k.nv * c->ob_grid.x * c->ob_nty, st));
     hipLaunchKernelGGL(k_regrid_mom0, dim3((unsigned)((npix + 255) / 256), nw), dim3(256), 0, st, k,
@@ -1944,7 +2015,7 @@ int run_group_mom0(slamhip_ctx* c, const double* d_params, int nw, double* d_chi
     HIP_TRY(c, hipGetLastError());
     return SLAMHIP_OK;
   }
-  if (c->ob_ty && c->conv_mode == 0) {
+  if (c->ob_ty && c->conv_mode != 1) {
     Timed t_(c, KID_CONV, st);
     dim3 g(c->ob_grid.x, (k.ny + c->ob_ty - 1) / c->ob_ty, c->ob_grid.z * nw);
 #define SLAM_OBS(TY_, NIT_, WR_)                                                            \
@@ -1985,7 +2056,9 @@ int run_group_mom0(slamhip_ctx* c, const double* d_params, int nw, double* d_chi
 int run_group(slamhip_ctx* c, const double* d_params, int nw, double* d_chi2,
               hipStream_t st) {
   if (c->k.mom0decon) return run_group_mom0(c, d_params, nw, d_chi2, nullptr, true, st);
-  const bool fused = c->fused && c->conv_mode == 0;
+  const bool fused = c->fused && c->conv_mode != 1;
+  // conv mode 2 keeps the factorised beam where mode 0 would take direct taps
+  const int fz_rank = (c->conv_mode == 2 && c->nrank >= 1) ? c->nrank : c->fz_rank;
   int rc = run_model(c, d_params, nw, st, !fused);
   if (rc) return rc;
   if (fused) {
@@ -1999,16 +2072,17 @@ int run_group(slamhip_ctx* c, const double* d_params, int nw, double* d_chi2,
     }
     {
       Timed t_(c, KID_CONV, st);
-      dim3 gz(c->persist_blocks, 1, 1);
-#define SLAM_FUSED(TY_, MR_)                                                              \
-      hipLaunchKernelGGL((k_conv_chi2<TY_, MR_>), gz, dim3(CV_NT), c->fz_lds, st, c->k,   \
+      dim3 gz(fz_rank ? c->persist_blocks : c->persist_direct, 1, 1);
+      const size_t fz_lds = fz_rank ? c->fz_lds : c->fz_lds_direct;
+#define SLAM_FUSED(TY_, MR_, DIR_)                                                        \
+      hipLaunchKernelGGL((k_conv_chi2<TY_, MR_, DIR_>), gz, dim3(CV_NT), fz_lds, st, c->k, \
                          c->d_iunif, c->d_cellx, c->d_fracx, c->d_celly, c->d_fracy,       \
                          c->d_livelist, c->d_livecount, (int)c->fz_grid.x, (int)c->fz_grid.y, \
-                         c->d_partial, c->kpad, c->nrank)
+                         c->d_partial, c->kpad, fz_rank)
       switch (c->sep_variant) {
-        case 0: SLAM_FUSED(64, 2); break;
-        case 1: SLAM_FUSED(64, 3); break;
-        default: SLAM_FUSED(32, 2); break;
+        case 0: if (fz_rank) SLAM_FUSED(64, 2, false); else SLAM_FUSED(64, 2, true); break;
+        case 1: if (fz_rank) SLAM_FUSED(64, 3, false); else SLAM_FUSED(64, 3, true); break;
+        default: if (fz_rank) SLAM_FUSED(32, 2, false); else SLAM_FUSED(32, 2, true); break;
       }
 #undef SLAM_FUSED
     }
@@ -2203,13 +2277,30 @@ int slamhip_create(const slamhip_desc* d, slamhip_ctx** out) {
     c->fz_lds += (size_t)(ty + c->kpad - 1) * (CONV_TX + 1) * sizeof(double);
     if (c->fz_lds > 156 * 1024) c->nrank = 0;
   }
-  if (c->nrank >= 1 && c->fz_lds > 48 * 1024 && c->sep_variant >= 0) {
-    const void* fz = c->sep_variant == 0 ? (const void*)k_conv_chi2<64, 2>
-                   : c->sep_variant == 1 ? (const void*)k_conv_chi2<64, 3>
-                                         : (const void*)k_conv_chi2<32, 2>;
-    HIP_TRY(c, hipFuncSetAttribute(fz, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->fz_lds));
+  // The fused kernel either applies the factorised beam or, when that takes
+  // many terms (a rotated Gaussian: ~14 for a 1e-13 tail, i.e. more
+  // multiply-adds than the K x K taps themselves, plus an intermediate),
+  // direct taps on the staged tile.
+  {
+    const size_t ty = c->sep_variant == 2 ? 32 : 64;
+    c->fz_lds_direct = std::max(c->sep_lds, 2 * ty * (CONV_TX + 1) * sizeof(double)) +
+                       (size_t)K * c->kpad * sizeof(double);
   }
-  c->fused = c->nrank >= 1 && c->sep_variant >= 0;
+  const bool direct_ok = c->sep_variant >= 0 && c->fz_lds_direct <= 156 * 1024;   // taps + tile fit the LDS
+  c->fz_rank = (c->nrank >= 1 && (c->nrank < DIRECT_MIN_RANK || !direct_ok)) ? c->nrank : 0;
+  if (c->sep_variant >= 0) {
+    const void* fz = c->sep_variant == 0 ? (const void*)k_conv_chi2<64, 2, false>
+                   : c->sep_variant == 1 ? (const void*)k_conv_chi2<64, 3, false>
+                                         : (const void*)k_conv_chi2<32, 2, false>;
+    const void* fd = c->sep_variant == 0 ? (const void*)k_conv_chi2<64, 2, true>
+                   : c->sep_variant == 1 ? (const void*)k_conv_chi2<64, 3, true>
+                                         : (const void*)k_conv_chi2<32, 2, true>;
+    if (c->nrank >= 1)
+      HIP_TRY(c, hipFuncSetAttribute(fz, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->fz_lds));
+    if (direct_ok)
+      HIP_TRY(c, hipFuncSetAttribute(fd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->fz_lds_direct));
+  }
+  c->fused = c->sep_variant >= 0 && (c->fz_rank >= 1 || direct_ok);
   {
     const int ty = c->sep_variant == 2 ? 32 : 64;
     c->fz_sx = CONV_TX - 1;
@@ -2242,6 +2333,13 @@ int slamhip_create(const slamhip_desc* d, slamhip_ctx** out) {
   if (d->mom0decon && (rc = dev_upload(c, &k.mom0decon, d->mom0decon, (size_t)k.ny * k.nx))) return rc;
   if ((rc = dev_upload(c, &k.gx_pad, gx.data(), gx.size()))) return rc;
   if ((rc = dev_upload(c, &k.gy_pad, gy.data(), gy.size()))) return rc;
+  {
+    std::vector<double> ft((size_t)K * c->kpad, 0.0);
+    for (int b = 0; b < K; ++b)
+      for (int a = 0; a < K; ++a)
+        ft[(size_t)b * c->kpad + a] = d->gaussbeam[(size_t)(K - 1 - a) * K + (K - 1 - b)];
+    if ((rc = dev_upload(c, &k.beam_ft, ft.data(), ft.size()))) return rc;
+  }
   if ((rc = dev_upload(c, &k.leaf, leaves.data(), leaves.size()))) return rc;
   if ((rc = dev_upload(c, &k.tile_goff, tile_goff.data(), tile_goff.size()))) return rc;
   if ((rc = dev_upload(c, &k.tile_nl, tile_nl.data(), tile_nl.size()))) return rc;
@@ -2317,6 +2415,8 @@ int slamhip_create(const slamhip_desc* d, slamhip_ctx** out) {
     HIP_TRY(c, hipGetDeviceProperties(&prop, c->device));
     const int per_cu = std::max(1, (int)((160 * 1024) / std::max<size_t>(c->fz_lds + 2048, 1)));
     c->persist_blocks = prop.multiProcessorCount * std::min(per_cu, 8);
+    const int per_cu_d = std::max(1, (int)((160 * 1024) / std::max<size_t>(c->fz_lds_direct + 2048, 1)));
+    c->persist_direct = prop.multiProcessorCount * std::min(per_cu_d, 8);
   }
   if ((rc = dev_alloc(c, &c->d_tile_ix, W * c->fz_grid.x * 2))) return rc;
   if ((rc = dev_alloc(c, &c->d_tile_jy, W * c->fz_grid.y * 2))) return rc;
@@ -2395,11 +2495,11 @@ int slamhip_profile_end(slamhip_ctx* c, double* total_ms, int64_t* launches) {
 
 int slamhip_beam_rank(slamhip_ctx* c) {
   if (!c) return SLAMHIP_ERR_ARG;
-  return c->fused ? c->nrank : 0;
+  return c->fused ? c->fz_rank : 0;
 }
 
 int slamhip_set_conv_mode(slamhip_ctx* c, int mode) {
-  if (!c || (mode != 0 && mode != 1)) return SLAMHIP_ERR_ARG;
+  if (!c || mode < 0 || mode > 2) return SLAMHIP_ERR_ARG;
   c->conv_mode = mode;
   return SLAMHIP_OK;
 }

@@ -152,6 +152,15 @@ def test_c2_rotated_beam_direct2d():
                        sigma=fit.sigma, pa=2.0, incl=60.0, rmax=synth.RMAX, signmajor=1,
                        signminor=1)
     np.testing.assert_allclose(got[0], orc.chi2_of(s, P[0]), rtol=1e-9)
+    # mode 0 took direct taps in the fused kernel (a rotated Gaussian needs ~14
+    # outer products); the factorised beam (2) and the dense taps (1) agree
+    assert fit.engine.beam_rank == 0
+    fit.engine.set_conv_mode(2)
+    np.testing.assert_allclose(fit.chi2_batch(P), got, rtol=1e-11)
+    fit.engine.set_conv_mode(1)
+    np.testing.assert_allclose(fit.chi2_batch(P), got, rtol=1e-11)
+    fit.engine.set_conv_mode(0)
+    assert np.array_equal(fit.chi2_batch(P[::-1])[::-1], got)
     fit.close()
 
 
