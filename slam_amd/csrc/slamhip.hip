@@ -44,6 +44,7 @@ constexpr int IDX_UNITS = 4;          // fast-index guard, in units of 2^-20
 constexpr double IDX_BIAS = 22.5 * 1048576.0 + IDX_UNITS + 6755399441055744.0;   // 22.5*2^20 + guard + 1.5*2^52
 constexpr int MAX_RANK = 24;                 // beam outer-product terms the fused kernel accepts
 constexpr unsigned LEAF_PAD = 0xffffffffu;    // slot without a sample
+constexpr int DIRECT_PITCH = (CONV_TX + 32 - 1) | 1;   // fused direct taps, kpad <= 32: LDS tile pitch
 constexpr int DIRECT_MIN_RANK = 6;           // beams needing this many terms or more get direct taps in the fused kernel
 constexpr int FLAG_MAX = 512;                // occupancy bytes one conv window may span
 
@@ -822,7 +823,7 @@ k_compact(FitK g, const unsigned char* __restrict__ winflag, int total,
 constexpr int CV_NT = 512;                   // threads per workgroup
 constexpr int CV_NW = CV_NT / 64;            // waves
 
-template <int TY, int MAXR, bool DIRECT>
+template <int TY, int MAXR, bool DIRECT, int PITCH = 0>   // PITCH: LDS tile pitch fixed at compile time (0: from kpad)
 __global__ void __launch_bounds__(CV_NT, 4)
 k_conv_chi2(FitK g, const double* __restrict__ iunif,
             const int* __restrict__ cellx, const double* __restrict__ fracx,
@@ -841,7 +842,8 @@ k_conv_chi2(FitK g, const double* __restrict__ iunif,
   __shared__ double sg[CV_NW], sf[CV_NW];
   const int K = g.kbeam, ng = g.ngauss, n = g.nneed;
   const int rows = TY + kpad - 1, cols = TX + kpad - 1;
-  const int P = cols | 1;
+  // a compile-time pitch turns the direct taps' row offsets into immediates
+  const int P = PITCH ? PITCH : (cols | 1);
   const int vrows = TY + K - 1, vcols = TX + K - 1;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave index, kept scalar
@@ -1045,9 +1047,19 @@ k_conv_chi2(FitK g, const double* __restrict__ iunif,
             bits = (lo >> sh) | (sh ? (hi << (64 - sh)) : 0ull);
           }
           if (!(bits & ((1ull << (RB + R - 1)) - 1ull))) continue;
+          // three row pointers the compiler cannot relate: rows 3 apart lie more
+          // than a ds_read2_b64's reach apart, so the reads stay single
+          // ds_read_b64 (2 LDS cycles each; the paired form costs 8)
+          int o1 = P, o2 = 2 * P;
+          asm volatile("" : "+v"(o1));
+          asm volatile("" : "+v"(o2));
+          const double* c0 = col + u0 * P;
+          const double* c1 = c0 + o1;
+          const double* c2 = c0 + o2;
           double win[RB + R - 1];
 #pragma unroll
-          for (int r = 0; r < RB + R - 1; ++r) win[r] = col[(u0 + r) * P];
+          for (int r = 0; r < RB + R - 1; ++r)
+            win[r] = (r % 3 == 0 ? c0 : r % 3 == 1 ? c1 : c2)[(r / 3) * 3 * P];
 #pragma unroll
           for (int qq = 0; qq < R; ++qq) {
             const double wgt = wb[u0 + qq];
@@ -1755,6 +1767,7 @@ struct slamhip_ctx {
   int nrank = 1;           // outer-product terms of the factorised beam (0: not factorised)
   int fz_rank = 1;         // what the fused kernel uses in conv mode 0: nrank, or 0 = direct taps
   size_t fz_lds_direct = 0;
+  bool direct_fixed = false;   // direct taps run the fixed-pitch instance
   int persist_direct = 1;
   size_t sep_lds = 0, c2d_lds = 0, fz_lds = 0;
   hipStream_t stream = nullptr;
@@ -2080,7 +2093,15 @@ int run_group(slamhip_ctx* c, const double* d_params, int nw, double* d_chi2,
                          c->d_livelist, c->d_livecount, (int)c->fz_grid.x, (int)c->fz_grid.y, \
                          c->d_partial, c->kpad, fz_rank)
       switch (c->sep_variant) {
-        case 0: if (fz_rank) SLAM_FUSED(64, 2, false); else SLAM_FUSED(64, 2, true); break;
+        case 0:
+          if (fz_rank) SLAM_FUSED(64, 2, false);
+          else if (c->direct_fixed)
+            hipLaunchKernelGGL((k_conv_chi2<64, 2, true, DIRECT_PITCH>), gz, dim3(CV_NT), fz_lds, st, c->k,
+                               c->d_iunif, c->d_cellx, c->d_fracx, c->d_celly, c->d_fracy,
+                               c->d_livelist, c->d_livecount, (int)c->fz_grid.x, (int)c->fz_grid.y,
+                               c->d_partial, c->kpad, fz_rank);
+          else SLAM_FUSED(64, 2, true);
+          break;
         case 1: if (fz_rank) SLAM_FUSED(64, 3, false); else SLAM_FUSED(64, 3, true); break;
         default: if (fz_rank) SLAM_FUSED(32, 2, false); else SLAM_FUSED(32, 2, true); break;
       }
@@ -2283,7 +2304,10 @@ int slamhip_create(const slamhip_desc* d, slamhip_ctx** out) {
   // direct taps on the staged tile.
   {
     const size_t ty = c->sep_variant == 2 ? 32 : 64;
-    c->fz_lds_direct = std::max(c->sep_lds, 2 * ty * (CONV_TX + 1) * sizeof(double)) +
+    // the common case (64-row windows, K <= 32) runs with the tile pitch fixed at DIRECT_PITCH
+    c->direct_fixed = c->sep_variant == 0 && c->kpad <= 32;
+    const size_t tile = c->direct_fixed ? (ty + c->kpad - 1) * DIRECT_PITCH * sizeof(double) : c->sep_lds;
+    c->fz_lds_direct = std::max(tile, 2 * ty * (CONV_TX + 1) * sizeof(double)) +
                        (size_t)K * c->kpad * sizeof(double);
   }
   const bool direct_ok = c->sep_variant >= 0 && c->fz_lds_direct <= 156 * 1024;   // taps + tile fit the LDS
@@ -2297,6 +2321,7 @@ int slamhip_create(const slamhip_desc* d, slamhip_ctx** out) {
                                          : (const void*)k_conv_chi2<32, 2, true>;
     if (c->nrank >= 1)
       HIP_TRY(c, hipFuncSetAttribute(fz, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->fz_lds));
+    if (c->direct_fixed) fd = (const void*)k_conv_chi2<64, 2, true, DIRECT_PITCH>;
     if (direct_ok)
       HIP_TRY(c, hipFuncSetAttribute(fd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->fz_lds_direct));
   }
