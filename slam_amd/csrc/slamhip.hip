@@ -895,8 +895,7 @@ k_conv_chi2(FitK g, const double* __restrict__ iunif,
     const int fnx = min(wx0 + vcols - 1, n - 1) / PT_X - ftx0 + 1;
     const int nocc = __builtin_amdgcn_readfirstlane(cur->nocc);
 
-    // -- 0. issue every global load of this window now: the occupied input
-    //       tiles (NSB per wave in registers) and what the regrid needs
+    // -- 0. issue the loads of the occupied input tiles now (NSB per wave in registers)
     double sv[NSB][4];
     int srr[NSB], scc[NSB];
 #pragma unroll
@@ -929,22 +928,6 @@ k_conv_chi2(FitK g, const double* __restrict__ iunif,
     double t1 = 0.0;
     double dv[NRQ], t0q[NRQ];
     int i0q[NRQ];
-    auto regrid_loads = [&]() {
-      if (ix < ixb) {
-        i1 = cellx[(long long)wi * g.nx + ix] - x0;
-        t1 = fracx[(long long)wi * g.nx + ix];
-      }
-#pragma unroll
-      for (int q = 0; q < NRQ; ++q) {
-        const int jy = jya + wv + CV_NW * q;
-        const bool rowin = jy < jyb;
-        i0q[q] = rowin ? celly[(long long)wi * g.ny + jy] - y0 : -1;   // wave-uniform
-        t0q[q] = rowin ? fracy[(long long)wi * g.ny + jy] : 0.0;
-        dv[q] = (ix < ixb && rowin) ? dat[(long long)jy * g.nx + ix] : 0.0;
-      }
-    };
-    // the direct taps need the registers: there the loads wait until the taps are done
-    if (!DIRECT) regrid_loads();
 
     // -- 1. rows that hold emission; zero them in the LDS tile
     auto uniform64 = [](unsigned long long v) {             // block-uniform value into SGPRs
@@ -1145,7 +1128,19 @@ k_conv_chi2(FitK g, const double* __restrict__ iunif,
         }
       }
     }
-    if (DIRECT) regrid_loads();
+    // what the regrid needs from HBM, requested only now: the passes above want the registers
+    if (ix < ixb) {
+      i1 = cellx[(long long)wi * g.nx + ix] - x0;
+      t1 = fracx[(long long)wi * g.nx + ix];
+    }
+#pragma unroll
+    for (int q = 0; q < NRQ; ++q) {
+      const int jy = jya + wv + CV_NW * q;
+      const bool rowin = jy < jyb;
+      i0q[q] = rowin ? celly[(long long)wi * g.ny + jy] - y0 : -1;   // wave-uniform
+      t0q[q] = rowin ? fracy[(long long)wi * g.ny + jy] : 0.0;
+      dv[q] = (ix < ixb && rowin) ? dat[(long long)jy * g.nx + ix] : 0.0;
+    }
     const bool xown = i1 >= 0 && i1 < TX - 1;               // else owned by another window
     __syncthreads();                                        // column pass done reading LDS
     if (DIRECT) {
