@@ -46,6 +46,7 @@ constexpr int MAX_RANK = 24;                 // beam outer-product terms the fus
 constexpr unsigned LEAF_PAD = 0xffffffffu;    // slot without a sample
 constexpr int DIRECT_PITCH = (CONV_TX + 32 - 1) | 1;   // fused direct taps, kpad <= 32: LDS tile pitch
 constexpr int DIRECT_MIN_RANK = 6;           // beams needing this many terms or more get direct taps in the fused kernel
+constexpr int PREP_TILES = 1024;             // conv windows per axis pair k_prep can index (ntx + nty)
 constexpr int FLAG_MAX = 512;                // occupancy bytes one conv window may span
 
 // ---------------------------------------------------------------------------
@@ -102,7 +103,7 @@ struct WalkerK {
 };
 
 // ---------------------------------------------------------------------------
-// k_prep: one 64-thread block per walker.
+// k_prep: one 256-thread block per walker.
 // ---------------------------------------------------------------------------
 __device__ inline double sgn(double x) { return (x > 0) - (x < 0); }
 
@@ -139,9 +140,17 @@ __global__ void k_prep(FitK g, const double* __restrict__ params, int nw,
                        WalkerK* __restrict__ wk, int* __restrict__ cellx,
                        double* __restrict__ fracx, int* __restrict__ celly,
                        double* __restrict__ fracy, int* __restrict__ tile_ix,
-                       int* __restrict__ tile_jy, int ntx, int nty, int sx, int sy) {
+                       int* __restrict__ tile_jy, int ntx, int nty, int sx, int sy,
+                       unsigned char* __restrict__ winflag, int winbytes, int* __restrict__ livecount) {
   const int w = blockIdx.x;
   if (w >= nw) return;
+  if (winflag) {
+    // the marks of this walker's conv windows and the live-window / ticket
+    // counters start every group at zero
+    unsigned char* wf = winflag + (long long)w * winbytes;
+    for (int i = threadIdx.x; i < winbytes; i += blockDim.x) wf[i] = 0;
+    if (w == 0 && threadIdx.x < 64) livecount[threadIdx.x] = 0;
+  }
   const double* p = params + (long long)w * NP;
   WalkerK& o = wk[w];
   const int t = threadIdx.x;
@@ -153,20 +162,28 @@ __global__ void k_prep(FitK g, const double* __restrict__ params, int nw,
     regrid_cell(g.yneed, g.nneed, g.yobs[j] - p[9], &celly[(long long)w * g.ny + j],
                 &fracy[(long long)w * g.ny + j]);
   // observed index range [lo, hi) whose cells fall in each conv tile's span
+  // (tile tt owns cells [tt*s, (tt+1)*s)): min / max over the observed indices
+  __shared__ int s_lo[PREP_TILES], s_hi[PREP_TILES];
+  const bool tiles_ok = ntx + nty <= PREP_TILES;           // else the fused kernel is not used (create)
+  for (int tl = t; tiles_ok && tl < ntx + nty; tl += blockDim.x) { s_lo[tl] = 0x7fffffff; s_hi[tl] = 0; }
   __syncthreads();
-  for (int tl = t; tl < ntx + nty; tl += blockDim.x) {
+  for (int i = t; tiles_ok && i < g.nx + g.ny; i += blockDim.x) {
+    const bool isx = i < g.nx;
+    const int ii = isx ? i : i - g.nx;
+    const int cell = isx ? cellx[(long long)w * g.nx + ii] : celly[(long long)w * g.ny + ii];
+    if (cell < 0) continue;                                // outside the model grid, or NaN
+    const int tt = cell / (isx ? sx : sy);
+    if (tt >= (isx ? ntx : nty)) continue;
+    atomicMin(&s_lo[isx ? tt : ntx + tt], ii);
+    atomicMax(&s_hi[isx ? tt : ntx + tt], ii + 1);
+  }
+  __syncthreads();
+  for (int tl = t; tiles_ok && tl < ntx + nty; tl += blockDim.x) {
     const bool isx = tl < ntx;
     const int tt = isx ? tl : tl - ntx;
-    const int c0 = tt * (isx ? sx : sy), c1 = c0 + (isx ? sx : sy);
-    const int* cell = isx ? &cellx[(long long)w * g.nx] : &celly[(long long)w * g.ny];
-    const int m = isx ? g.nx : g.ny;
-    int lo = m, hi = 0;
-    for (int i = 0; i < m; ++i)
-      if (cell[i] >= c0 && cell[i] < c1) { lo = min(lo, i); hi = max(hi, i + 1); }
-    if (hi == 0) lo = 0;
     int* o2 = isx ? &tile_ix[((long long)w * ntx + tt) * 2] : &tile_jy[((long long)w * nty + tt) * 2];
-    o2[0] = lo;
-    o2[1] = hi;
+    o2[0] = s_hi[tl] == 0 ? 0 : s_lo[tl];
+    o2[1] = s_hi[tl];
   }
   const double cs = p[2];
   // update_prof (:412-427)
@@ -1967,14 +1984,12 @@ int run_model(slamhip_ctx* c, const double* d_params, int nw, hipStream_t st, bo
   const FitK& k = c->k;
   if (dense)
     HIP_TRY(c, hipMemsetAsync(c->d_iunif, 0, sizeof(double) * (size_t)nw * k.nv * k.nneed * k.nneed, st));
-  // window marks + live counter start at zero every group
-  HIP_TRY(c, hipMemsetAsync(c->d_winflag, 0, (size_t)nw * k.nv * c->fz_grid.x * c->fz_grid.y, st));
-  HIP_TRY(c, hipMemsetAsync(c->d_livecount, 0, 256, st));
   {
     Timed t_(c, KID_PREP, st);
-    hipLaunchKernelGGL(k_prep, dim3(nw), dim3(64), 0, st, k, d_params, nw, c->d_wk,
+    hipLaunchKernelGGL(k_prep, dim3(nw), dim3(256), 0, st, k, d_params, nw, c->d_wk,
                        c->d_cellx, c->d_fracx, c->d_celly, c->d_fracy, c->d_tile_ix,
-                       c->d_tile_jy, (int)c->fz_grid.x, (int)c->fz_grid.y, c->fz_sx, c->fz_sy);
+                       c->d_tile_jy, (int)c->fz_grid.x, (int)c->fz_grid.y, c->fz_sx, c->fz_sy,
+                       c->d_winflag, (int)(k.nv * c->fz_grid.x * c->fz_grid.y), c->d_livecount);
   }
   {
     Timed t_(c, KID_SURFACE, st);
@@ -2425,6 +2440,7 @@ int slamhip_create(const slamhip_desc* d, slamhip_ctx** out) {
     const int ty = c->sep_variant == 2 ? 32 : 64;
     const int spanx = (CONV_TX + K - 2) / PT_X + 2, spany = (ty + K - 2) / PT_Y + 2;
     if (c->fused && spanx * spany > FLAG_MAX) c->fused = 0;
+    if ((int)(c->fz_grid.x + c->fz_grid.y) > PREP_TILES) c->fused = 0;
   }
   {
     const size_t nwin = W * k.nv * c->fz_grid.x * c->fz_grid.y;
@@ -2669,9 +2685,10 @@ int slamhip_surface(slamhip_ctx* c, const double* params, int slot, double* x_ou
   if (rc) return rc;
   if (slot < 0 || slot > 3 || !x_out || !v_out) return fail(c, SLAMHIP_ERR_ARG, "surface: bad arguments");
   const FitK& k = c->k;
-  hipLaunchKernelGGL(k_prep, dim3(1), dim3(64), 0, c->stream, k, c->d_params, 1, c->d_wk,
+  hipLaunchKernelGGL(k_prep, dim3(1), dim3(256), 0, c->stream, k, c->d_params, 1, c->d_wk,
                      c->d_cellx, c->d_fracx, c->d_celly, c->d_fracy, c->d_tile_ix,
-                     c->d_tile_jy, (int)c->fz_grid.x, (int)c->fz_grid.y, c->fz_sx, c->fz_sy);
+                     c->d_tile_jy, (int)c->fz_grid.x, (int)c->fz_grid.y, c->fz_sx, c->fz_sy,
+                     (unsigned char*)nullptr, 0, (int*)nullptr);
   WalkerK hw;
   HIP_TRY(c, hipMemcpyAsync(&hw, c->d_wk, sizeof hw, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -2696,9 +2713,10 @@ int slamhip_prof(slamhip_ctx* c, double cs, double* prof_out, double* prof_d_out
   double p[NP] = {1, 1, cs, 0, -1, 0, 0, 0, 0, 0, 0, 0, 0};
   int rc = single_prepare(c, p);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_prep, dim3(1), dim3(64), 0, c->stream, c->k, c->d_params, 1, c->d_wk,
+  hipLaunchKernelGGL(k_prep, dim3(1), dim3(256), 0, c->stream, c->k, c->d_params, 1, c->d_wk,
                      c->d_cellx, c->d_fracx, c->d_celly, c->d_fracy, c->d_tile_ix,
-                     c->d_tile_jy, (int)c->fz_grid.x, (int)c->fz_grid.y, c->fz_sx, c->fz_sy);
+                     c->d_tile_jy, (int)c->fz_grid.x, (int)c->fz_grid.y, c->fz_sx, c->fz_sy,
+                     (unsigned char*)nullptr, 0, (int*)nullptr);
   WalkerK hw;
   HIP_TRY(c, hipMemcpyAsync(&hw, c->d_wk, sizeof hw, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
