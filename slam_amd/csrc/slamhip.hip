@@ -1742,7 +1742,8 @@ struct slamhip_ctx {
   double* d_params = nullptr;
   double2* d_geom = nullptr;   // [walker][surface][sample] {vlos*sqrt(M), weight}
   double* d_iunif = nullptr;
-  double* d_iconv = nullptr;
+  double* d_iconv = nullptr;   // dense convolved cubes: one walker at create, grown on demand (dense mode only)
+  int iconv_walkers = 0;
   double* d_obs = nullptr;     // 'mom0*' scalings: [walker][nv][ny][nx] regridded cube
   dim3 ob_grid{1, 1, 1};       // k_conv_obs grid for ONE walker (z = nv)
   int ob_blocks = 0;
@@ -1977,6 +1978,24 @@ int run_conv(slamhip_ctx* c, const double* in, double* out, int planes,
   return SLAMHIP_OK;
 }
 
+// The dense (non-fused) path keeps whole convolved cubes; the hot path never
+// does, so that buffer only grows when the dense path is asked for a batch.
+int ensure_iconv(slamhip_ctx* c, int nw) {
+  if (nw <= c->iconv_walkers) return SLAMHIP_OK;
+  HIP_TRY(c, hipDeviceSynchronize());            // the old buffer may still be read
+  if (c->d_iconv) {
+    (void)hipFree(c->d_iconv);
+    c->allocs.erase(std::remove(c->allocs.begin(), c->allocs.end(), (void*)c->d_iconv), c->allocs.end());
+    c->d_iconv = nullptr;
+    c->iconv_walkers = 0;
+  }
+  const size_t per = (size_t)c->k.nv * c->k.nneed * c->k.nneed;
+  int rc = dev_alloc(c, &c->d_iconv, per * nw);
+  if (rc) return rc;
+  c->iconv_walkers = nw;
+  return SLAMHIP_OK;
+}
+
 // Stages shared by every entry point: params (device) -> iunif for `nw` walkers
 // `dense`: the consumer reads Iunif without the occupancy flags, so tiles that
 // k_profile skips must already hold zeros.
@@ -2126,6 +2145,7 @@ int run_group(slamhip_ctx* c, const double* d_params, int nw, double* d_chi2,
     HIP_TRY(c, hipGetLastError());
     return SLAMHIP_OK;
   }
+  if ((rc = ensure_iconv(c, nw))) return rc;
   rc = run_conv(c, c->d_iunif, c->d_iconv, nw * c->k.nv, st);
   if (rc) return rc;
   {
@@ -2380,13 +2400,13 @@ int slamhip_create(const slamhip_desc* d, slamhip_ctx** out) {
   if ((rc = dev_upload(c, &k.tile_nl, tile_nl.data(), tile_nl.size()))) return rc;
 
   // --- per-group scratch -----------------------------------------------------
-  const size_t per_walker = sizeof(double) * (8 * (size_t)k.nslot + 2 * (size_t)k.nv * n * n +
+  const size_t per_walker = sizeof(double) * (8 * (size_t)k.nslot + (size_t)k.nv * n * n +
                                               (d->mom0decon ? ncube : 0));
   size_t freeb = 0, totalb = 0;
   HIP_TRY(c, hipMemGetInfo(&freeb, &totalb));
-  size_t budget = d->max_scratch_bytes > 0 ? (size_t)d->max_scratch_bytes : ((size_t)24 << 30);
+  size_t budget = d->max_scratch_bytes > 0 ? (size_t)d->max_scratch_bytes : ((size_t)64 << 30);
   budget = std::min(budget, freeb / 10 * 7);
-  c->wgroup = (int)std::max<size_t>(1, std::min<size_t>(32, budget / per_walker));
+  c->wgroup = (int)std::max<size_t>(1, std::min<size_t>(128, budget / per_walker));
   // keep conv's grid.z within limits
   while (c->wgroup > 1 && (long long)c->wgroup * k.nv > 32768) --c->wgroup;
   c->rg_grid = dim3((k.nx + RED_THREADS - 1) / RED_THREADS, (k.ny + RG_ROWS - 1) / RG_ROWS, k.nv);
@@ -2422,7 +2442,7 @@ int slamhip_create(const slamhip_desc* d, slamhip_ctx** out) {
   if ((rc = dev_alloc(c, &c->d_params, W * NP))) return rc;
   if ((rc = dev_alloc(c, &c->d_geom, W * 4 * k.nslot))) return rc;
   if ((rc = dev_alloc(c, &c->d_iunif, W * k.nv * n * n))) return rc;
-  if ((rc = dev_alloc(c, &c->d_iconv, W * k.nv * n * n))) return rc;
+  if ((rc = ensure_iconv(c, 1))) return rc;
   if (d->mom0decon && (rc = dev_alloc(c, &c->d_obs, W * ncube))) return rc;
   if ((rc = dev_alloc(c, &c->d_partial, W * max_blocks * 3))) return rc;
   if ((rc = dev_alloc(c, &c->d_stats, W * 6))) return rc;
