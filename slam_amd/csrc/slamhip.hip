@@ -758,7 +758,7 @@ k_conv_sep(FitK g, const double* __restrict__ in, double* __restrict__ out,
     }
 }
 
-constexpr int WIN_IDS = 32;
+constexpr int WIN_IDS = 56;           // covers every tile under a 64-row window of a K <= 32 beam
 // One live conv window, everything k_conv_chi2 needs to start loading at once.
 struct __attribute__((aligned(16))) WinDesc {
   int e;                         // window id: (walker*nv + channel)*wnx*wny + by*wnx + bx
@@ -854,7 +854,7 @@ k_conv_chi2(FitK g, const double* __restrict__ iunif,
   constexpr int TX = CONV_TX, R = CONV_R, PC = TX + 1, P2 = TX + 1;
   constexpr bool direct = DIRECT;
   constexpr int NRQ = (TY - 1 + CV_NW - 1) / CV_NW;         // regrid rows per wave
-  constexpr int NSB = 2;                                    // staged tiles per wave held in registers
+  constexpr int NSB = 7;                                    // staged tiles per wave held in registers
   __shared__ unsigned char s_rowlist[256];
   __shared__ double sg[CV_NW], sf[CV_NW];
   const int K = g.kbeam, ng = g.ngauss, n = g.nneed;
