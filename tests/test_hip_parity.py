@@ -161,6 +161,20 @@ def test_chi2_batch_vs_oracle_random(case):
     np.testing.assert_allclose(got, ref, rtol=CHI2_TOL)
 
 
+def test_scratch_cap_splits_the_batch(case):
+    """A small `max_scratch_bytes` forces one walker per launch group; walkers are
+    independent, so chi2 is bitwise the same as with the default groups."""
+    from slam_amd import HipLikelihood
+    g, s, eng = case
+    P = np.tile(np.array([0.5, 150, 0.4, 0.1, 0.3, 1, 0, 0, 0, 0, 0, 0, 0.]), (5, 1))
+    P[:, 0] = [0.2, 0.4, 0.6, 0.8, 1.0]
+    P[:, 3] = [0.0, 0.05, 0.1, 0.2, 0.3]
+    want = eng.chi2_batch(P)
+    with HipLikelihood(engine_setup(s), max_scratch_bytes=1) as small:
+        assert small.walkers_per_group == 1
+        assert np.array_equal(small.chi2_batch(P), want)
+
+
 def test_empty_batch(case):
     g, s, eng = case
     assert eng.chi2_batch(np.zeros((0, 13))).shape == (0,)
