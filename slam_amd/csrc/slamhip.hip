@@ -40,8 +40,15 @@ constexpr int CH = 16;                       // channels accumulated in register
 constexpr int CONV_TX = 64;                  // conv tile width (= one wave)
 constexpr int CONV_R = 8;                    // outputs per thread along the tap axis
 constexpr int RED_THREADS = 256;
-constexpr int IDX_UNITS = 4;          // fast-index guard, in units of 2^-20
-constexpr double IDX_BIAS = 22.5 * 1048576.0 + IDX_UNITS + 6755399441055744.0;   // 22.5*2^20 + guard + 1.5*2^52
+// Fixed-point table index of k_profile: t (table steps) is formed as
+// (t + IDX_OFF) * 2^32 + IDX_FGUARD + 2^52, a double in [2^52, 2^53) whose low
+// mantissa word is t's fraction in units of 2^-32 and whose HIGH word is
+// IDX_HI0 + floor(t) + IDX_OFF.
+constexpr double IDX_SCALE = 4294967296.0;            // 2^32
+constexpr int IDX_OFF = 2048;                         // makes the scaled value positive (|t| < 2^11)
+constexpr unsigned IDX_FGUARD = 4096;                 // guard, in units of 2^-32 table steps
+constexpr double IDX_BIAS = (22.5 + IDX_OFF) * IDX_SCALE + IDX_FGUARD + 4503599627370496.0;   // ... + 2^52
+constexpr int IDX_HI0 = 0x43300000 + IDX_OFF;         // high word of the sum for floor(t) = 0
 constexpr int MAX_RANK = 24;                 // beam outer-product terms the fused kernel accepts
 constexpr unsigned LEAF_PAD = 0xffffffffu;    // slot without a sample
 constexpr int DIRECT_PITCH = (CONV_TX + 32 - 1) | 1;   // fused direct taps, kpad <= 32: LDS tile pitch
@@ -62,7 +69,7 @@ struct FitK {
   double ssq_data;      // sum(data_valid^2), fixed per fit
   int data_has_nan;
   int fast_idx;         // k_profile may use the fixed-point table index
-  double* tk;           // per-group scratch [walker][nvpad]: v_k * rinv * 2^20 (k_prep -> k_profile)
+  double* tk;           // per-group scratch [walker][nvpad]: v_k * rinv * 2^32 (k_prep -> k_profile)
   const double* Xnest0;
   const double* Ynest0;
   const double* xneed;
@@ -206,11 +213,11 @@ __global__ void k_prep(FitK g, const double* __restrict__ params, int nw,
     o.prof[t] = val;
   }
   {
-    // channel velocities in units of 2^-20 table steps, for k_profile's
+    // channel velocities in units of 2^-32 table steps, for k_profile's
     // fixed-point index; padding channels land on prof[44] = 0
-    const double R = (1.0 / (g.dv * d)) * 1048576.0;
+    const double R = (1.0 / (g.dv * d)) * IDX_SCALE;
     for (int k = t; k < g.nvpad; k += blockDim.x)
-      g.tk[(long long)w * g.nvpad + k] = k < g.nv ? g.vpad[k] * R : 1000.0 * 1048576.0;
+      g.tk[(long long)w * g.nvpad + k] = k < g.nv ? g.vpad[k] * R : 1000.0 * IDX_SCALE;
   }
   if (t == 0) {
     const double Mstar = p[0], Rc = p[1], h1 = p[3], h2v = p[4], pI = p[5];
@@ -477,7 +484,7 @@ k_profile(FitK g, const WalkerK* __restrict__ wk, const double2* __restrict__ ge
     for (int c = 0; c < CH; ++c) vks[c] = FAST ? 0.0 : vk[c];
     // fast table index (FAST: create checked that every |t| of a lit block is
     // below 2^11): this block's channels as k_prep scaled them, block-uniform
-    const double R = rinv * 1048576.0;
+    const double R = rinv * IDX_SCALE;
     const double* __restrict__ tkp = g.tk + (long long)wi * g.nvpad + cix * CH;
     double tks[CH];
 #pragma unroll
@@ -506,21 +513,21 @@ k_profile(FitK g, const WalkerK* __restrict__ wk, const double2* __restrict__ ge
         int idx[CH];
         bool near = false;
         if (FAST) {
-          // t*2^20 rounded to an integer in the low mantissa bits of
-          // (t*2^20 + 1.5*2^52): idx = u >> 20, fraction = u & (2^20-1).  The
-          // sum carries at most one unit (2^-20) of rounding error; lanes within
-          // IDX_UNITS of an integer redo the index exactly.
-          // (the bias also carries +IDX_UNITS: "near" is then fraction < 2*IDX_UNITS,
-          // and u >> 20 is the index whenever the lane is not near)
+          // one fp64 add per channel (see IDX_BIAS): the low word of the sum is
+          // t's fraction, the high word its integer part + IDX_HI0, kept in that
+          // form until the clamp.  The sum is off by at most one unit of 2^-32 and
+          // the fast t by < 1e-11 from the reference's; the bias carries
+          // +IDX_FGUARD, so "near an integer" is fraction < 2*IDX_FGUARD, and the
+          // high word is the reference's index whenever the lane is not near.
           const double base = fma(-o, R, IDX_BIAS);
-          unsigned lowest = 0xFFFFFu;
+          unsigned lowest = 0xFFFFFFFFu;
 #pragma unroll
           for (int c = 0; c < CH; ++c) {
-            const int u = __double2loint(tks[c] + base);
-            lowest = min(lowest, (unsigned)u & 0xFFFFFu);
-            idx[c] = u >> 20;
+            const double sum = tks[c] + base;
+            lowest = min(lowest, (unsigned)__double2loint(sum));
+            idx[c] = __double2hiint(sum);
           }
-          near = lowest < 2u * IDX_UNITS;
+          near = lowest < 2u * IDX_FGUARD;
         } else {
 #pragma unroll
           for (int c = 0; c < CH; ++c) {
@@ -536,11 +543,13 @@ k_profile(FitK g, const WalkerK* __restrict__ wk, const double2* __restrict__ ge
             double v = (FAST ? vk[c] : vks[c]) - vl;
             v = v - voff;
             idx[c] = (int)(v / g.dv / w.prof_d + 22.0 + 0.5);
+            if (FAST) idx[c] = min(max(idx[c], 0), PROF_N) + IDX_HI0;
           }
         }
+        constexpr int I0 = FAST ? IDX_HI0 : 0;            // FAST: idx holds IDX_HI0 + index
 #pragma unroll
         for (int c = 0; c < CH; ++c)
-          acc[c] = fma(s_prof[min(max(idx[c], 0), PROF_N)], wt, acc[c]);
+          acc[c] = fma(s_prof[min(max(idx[c], I0), I0 + PROF_N) - I0], wt, acc[c]);
       }
     }
     if (!__syncthreads_or(hit)) {                         // empty sky in this channel block
