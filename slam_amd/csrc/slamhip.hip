@@ -473,7 +473,9 @@ k_profile(FitK g, const WalkerK* __restrict__ wk, const double2* __restrict__ ge
   __syncthreads();                                        // s_prof ready
   {
     const int kf = cix * CH + tid;                        // flag writer: thread c -> channel c
-    const double cmin = g.ch_vmin[cix], cmax = g.ch_vmax[cix];
+    // a sample lights the block only if vlos + voff lies within hw of [cmin, cmax]
+    const double cmid = 0.5 * (g.ch_vmin[cix] + g.ch_vmax[cix]);
+    const double hwc = hw + 0.5 * (g.ch_vmax[cix] - g.ch_vmin[cix]);
     const double* vk = g.vpad + cix * CH;
     double acc[CH];
 #pragma unroll
@@ -506,7 +508,7 @@ k_profile(FitK g, const WalkerK* __restrict__ wk, const double2* __restrict__ ge
         const double vl = s == 0 ? q[0].x : s == 1 ? q[1].x : s == 2 ? q[2].x : q[3].x;
         const double wt = s == 0 ? q[0].y : s == 1 ? q[1].y : s == 2 ? q[2].y : q[3].y;
         const double o = vl + voff;
-        if (cmin - o > hw || o - cmax > hw) continue;     // no channel of this block is lit
+        if (fabs(o - cmid) > hwc) continue;               // no channel of this block is lit
         hit = true;
         // table index of every channel, fast form (differs from the reference's
         // iv by < 1e-12); lanes within IDX_GUARD of an integer redo it exactly
@@ -542,14 +544,15 @@ k_profile(FitK g, const WalkerK* __restrict__ wk, const double2* __restrict__ ge
           for (int c = 0; c < CH; ++c) {
             double v = (FAST ? vk[c] : vks[c]) - vl;
             v = v - voff;
-            idx[c] = (int)(v / g.dv / w.prof_d + 22.0 + 0.5);
-            if (FAST) idx[c] = min(max(idx[c], 0), PROF_N) + IDX_HI0;
+            const int ix = (int)(v / g.dv / w.prof_d + 22.0 + 0.5);
+            acc[c] = fma(s_prof[min(max(ix, 0), PROF_N)], wt, acc[c]);
           }
-        }
-        constexpr int I0 = FAST ? IDX_HI0 : 0;            // FAST: idx holds IDX_HI0 + index
+        } else {
+          constexpr int I0 = FAST ? IDX_HI0 : 0;          // FAST: idx holds IDX_HI0 + index
 #pragma unroll
-        for (int c = 0; c < CH; ++c)
-          acc[c] = fma(s_prof[min(max(idx[c], I0), I0 + PROF_N) - I0], wt, acc[c]);
+          for (int c = 0; c < CH; ++c)
+            acc[c] = fma(s_prof[min(max(idx[c], I0), I0 + PROF_N) - I0], wt, acc[c]);
+        }
       }
     }
     if (!__syncthreads_or(hit)) {                         // empty sky in this channel block
