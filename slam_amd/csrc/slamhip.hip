@@ -503,10 +503,10 @@ k_profile(FitK g, const WalkerK* __restrict__ wk, const double2* __restrict__ ge
         for (int s = 0; s < 4; ++s)
           qn[s] = s < nsurf ? gw[(long long)s * g.nslot + (i + 1) * 256] : make_double2(VL_MASKED, 0.0);
       }
-#pragma unroll 1
-      for (int s = 0; s < nsurf; ++s) {
-        const double vl = s == 0 ? q[0].x : s == 1 ? q[1].x : s == 2 ? q[2].x : q[3].x;
-        const double wt = s == 0 ? q[0].y : s == 1 ? q[1].y : s == 2 ? q[2].y : q[3].y;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        if (s >= nsurf) continue;
+        const double vl = q[s].x, wt = q[s].y;
         const double o = vl + voff;
         if (fabs(o - cmid) > hwc) continue;               // no channel of this block is lit
         hit = true;
