@@ -858,7 +858,9 @@ k_conv_chi2(FitK g, const double* __restrict__ iunif,
             const int* __restrict__ cellx, const double* __restrict__ fracx,
             const int* __restrict__ celly, const double* __restrict__ fracy,
             const WinDesc* __restrict__ list, int* __restrict__ count, int wnx, int wny,
-            double* __restrict__ partial, int kpad, int nrank) {
+            double* __restrict__ partial, int kpad, int nrank,
+            const double* __restrict__ gxp, const double* __restrict__ gyp,
+            const double* __restrict__ gbt) {
   // DIRECT (nrank == 0): the beam is not worth factorising (a rotated Gaussian
   // needs ~14 terms): direct K x K taps on the staged tile instead of row +
   // column passes
@@ -885,8 +887,6 @@ k_conv_chi2(FitK g, const double* __restrict__ iunif,
   double* wyl = wxl + nrank * kpad;
   double* tmp = nrank == 1 ? lds : wyl + nrank * kpad;      // [rows][P2]
   for (int e = tid; e < nrank * kpad; e += CV_NT) { wxl[e] = g.gx_pad[e]; wyl[e] = g.gy_pad[e]; }
-  if (direct)                                               // [K][kpad] taps, after the tile
-    for (int e = tid; e < K * kpad; e += CV_NT) wxl[e] = g.beam_ft[e];
   __syncthreads();
   const int nlive = *count;
   constexpr int DW = sizeof(WinDesc) / 4;                   // descriptor dwords
@@ -1047,7 +1047,7 @@ k_conv_chi2(FitK g, const double* __restrict__ iunif,
       // sliding pass along y (lanes <-> x; RB+R-1 tile reads and R tap reads per
       // RB*R multiply-adds); tap blocks over rows without emission are skipped
       for (int b = tapset; b < K; b += 2) {
-        const double* wb = wxl + b * kpad;                  // LDS, same address in every lane
+        const double* __restrict__ wb = gbt + b * kpad;     // block-uniform address: scalar loads
         const double* col = lds + (rb * RB) * P + lane + b;
         for (int u0 = 0; u0 < kpad; u0 += R) {
           const int ra = rb * RB + u0;
@@ -1082,8 +1082,9 @@ k_conv_chi2(FitK g, const double* __restrict__ iunif,
       }
     }
     for (int rk = 0; !DIRECT && rk < nrank; ++rk) {
-      const double* wxr = wxl + rk * kpad;
-      const double* wyr = wyl + rk * kpad;
+      // taps through the scalar cache (block-uniform addresses): the LDS is busy enough
+      const double* __restrict__ wxr = gxp + rk * kpad;
+      const double* __restrict__ wyr = gyp + rk * kpad;
       double res[MAXR][R];
 #pragma unroll
       for (int q = 0; q < MAXR; ++q) {
@@ -2132,7 +2133,7 @@ int run_group(slamhip_ctx* c, const double* d_params, int nw, double* d_chi2,
       hipLaunchKernelGGL((k_conv_chi2<TY_, MR_, DIR_>), gz, dim3(CV_NT), fz_lds, st, c->k, \
                          c->d_iunif, c->d_cellx, c->d_fracx, c->d_celly, c->d_fracy,       \
                          c->d_livelist, c->d_livecount, (int)c->fz_grid.x, (int)c->fz_grid.y, \
-                         c->d_partial, c->kpad, fz_rank)
+                         c->d_partial, c->kpad, fz_rank, c->k.gx_pad, c->k.gy_pad, c->k.beam_ft)
       switch (c->sep_variant) {
         case 0:
           if (fz_rank) SLAM_FUSED(64, 2, false);
@@ -2140,7 +2141,7 @@ int run_group(slamhip_ctx* c, const double* d_params, int nw, double* d_chi2,
             hipLaunchKernelGGL((k_conv_chi2<64, 2, true, DIRECT_PITCH>), gz, dim3(CV_NT), fz_lds, st, c->k,
                                c->d_iunif, c->d_cellx, c->d_fracx, c->d_celly, c->d_fracy,
                                c->d_livelist, c->d_livecount, (int)c->fz_grid.x, (int)c->fz_grid.y,
-                               c->d_partial, c->kpad, fz_rank);
+                               c->d_partial, c->kpad, fz_rank, c->k.gx_pad, c->k.gy_pad, c->k.beam_ft);
           else SLAM_FUSED(64, 2, true);
           break;
         case 1: if (fz_rank) SLAM_FUSED(64, 3, false); else SLAM_FUSED(64, 3, true); break;
@@ -2349,8 +2350,7 @@ int slamhip_create(const slamhip_desc* d, slamhip_ctx** out) {
     // the common case (64-row windows, K <= 32) runs with the tile pitch fixed at DIRECT_PITCH
     c->direct_fixed = c->sep_variant == 0 && c->kpad <= 32;
     const size_t tile = c->direct_fixed ? (ty + c->kpad - 1) * DIRECT_PITCH * sizeof(double) : c->sep_lds;
-    c->fz_lds_direct = std::max(tile, 2 * ty * (CONV_TX + 1) * sizeof(double)) +
-                       (size_t)K * c->kpad * sizeof(double);
+    c->fz_lds_direct = std::max(tile, 2 * ty * (CONV_TX + 1) * sizeof(double));
   }
   const bool direct_ok = c->sep_variant >= 0 && c->fz_lds_direct <= 156 * 1024;   // taps + tile fit the LDS
   c->fz_rank = (c->nrank >= 1 && (c->nrank < DIRECT_MIN_RANK || !direct_ok)) ? c->nrank : 0;
