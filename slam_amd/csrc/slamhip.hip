@@ -1554,7 +1554,8 @@ template <int TY, int NIT, bool WRITE>
 __global__ void __launch_bounds__(256)
 k_conv_obs_sep(FitK g, const double* __restrict__ in, double* __restrict__ out,
                double* __restrict__ partial, int kpad, int nrank,
-               const unsigned char* __restrict__ tileflag, const double* __restrict__ empty_ss) {
+               const unsigned char* __restrict__ tileflag, const double* __restrict__ empty_ss,
+               const double* __restrict__ gxp, const double* __restrict__ gyp) {
   extern __shared__ double lds[];
   constexpr int TX = C2_TX;
   const int K = g.kbeam, ng = g.ngauss, nx = g.nx, ny = g.ny;
@@ -1621,8 +1622,9 @@ k_conv_obs_sep(FitK g, const double* __restrict__ in, double* __restrict__ out,
   if (live) {
     const int nitem = rows * (TX / R);
     for (int rk = 0; rk < nrank; ++rk) {
-      const double* wx = g.gx_pad + (long long)rk * kpad;
-      const double* wy = g.gy_pad + (long long)rk * kpad;
+      // taps as kernel arguments: block-uniform addresses -> scalar loads
+      const double* __restrict__ wx = gxp + (long long)rk * kpad;
+      const double* __restrict__ wy = gyp + (long long)rk * kpad;
       if (rk) __syncthreads();
       // row pass: tmp[row][x] = sum_u wx[u] * tile[row][x+u]; an item is R
       // neighbouring x of one row, lanes <-> rows (odd pitch: no bank conflicts).
@@ -2075,7 +2077,7 @@ int run_group_mom0(slamhip_ctx* c, const double* d_params, int nw, double* d_chi
     dim3 g(c->ob_grid.x, (k.ny + c->ob_ty - 1) / c->ob_ty, c->ob_grid.z * nw);
 #define SLAM_OBS(TY_, NIT_, WR_)                                                            \
     hipLaunchKernelGGL((k_conv_obs_sep<TY_, NIT_, WR_>), g, dim3(256), c->ob_lds, st, k, c->d_obs, \
-                       d_model, c->d_partial, c->kpad, c->nrank, c->d_obflag, c->d_obempty)
+                       d_model, c->d_partial, c->kpad, c->nrank, c->d_obflag, c->d_obempty, k.gx_pad, k.gy_pad)
     if (c->ob_ty == 32 && c->ob_nit == 2) { if (d_model) SLAM_OBS(32, 2, true); else SLAM_OBS(32, 2, false); }
     else if (c->ob_ty == 32)              { if (d_model) SLAM_OBS(32, 4, true); else SLAM_OBS(32, 4, false); }
     else                                  { if (d_model) SLAM_OBS(16, 4, true); else SLAM_OBS(16, 4, false); }
@@ -2501,7 +2503,7 @@ int slamhip_create(const slamhip_desc* d, slamhip_ctx** out) {
 #define SLAM_OBS0(TY_, NIT_)                                                                 \
     hipLaunchKernelGGL((k_conv_obs_sep<TY_, NIT_, false>), g, dim3(256), c->ob_lds, c->stream, k, \
                        c->d_obs, (double*)nullptr, c->d_obempty, c->kpad, c->nrank,          \
-                       (const unsigned char*)nullptr, (const double*)nullptr)
+                       (const unsigned char*)nullptr, (const double*)nullptr, k.gx_pad, k.gy_pad)
     if (c->ob_ty == 32 && c->ob_nit == 2) SLAM_OBS0(32, 2);
     else if (c->ob_ty == 32) SLAM_OBS0(32, 4);
     else SLAM_OBS0(16, 4);
