@@ -792,7 +792,15 @@ k_compact(FitK g, const unsigned char* __restrict__ winflag, int total,
           int wnx, int wny, int sx, int sy, int ty,
           WinDesc* __restrict__ list, int* __restrict__ count) {
   const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= total || !winflag[e]) return;
+  // one counter update per wave (a single address takes ~1 atomic per clock):
+  // lane 0 reserves the wave's slots, each live lane takes its rank among them
+  const bool live = e < total && winflag[e];
+  const unsigned long long lanes = __ballot(live);
+  const int lane = threadIdx.x & 63;
+  int slot = 0;
+  if (lane == 0 && lanes) slot = atomicAdd(count, __popcll(lanes));
+  slot = __shfl(slot, 0, 64) + __popcll(lanes & ((1ull << lane) - 1ull));
+  if (!live) return;
   const int n = g.nneed;
   const int z = e / (wnx * wny), tl = e - z * (wnx * wny);
   const int tby = tl / wnx, tbx = tl - tby * wnx;
@@ -802,40 +810,71 @@ k_compact(FitK g, const unsigned char* __restrict__ winflag, int total,
   const int ftx0 = max(wx0, 0) / PT_X, fty0 = max(wy0, 0) / PT_Y;
   const int fnx = min(wx0 + vcols - 1, n - 1) / PT_X - ftx0 + 1;
   const int fny = min(wy0 + vrows - 1, n - 1) / PT_Y - fty0 + 1;
-  WinDesc d;
-  d.e = e;
-  d.ixa = tile_ix[((long long)wi * wnx + tbx) * 2];
-  d.ixb = tile_ix[((long long)wi * wnx + tbx) * 2 + 1];
-  d.jya = tile_jy[((long long)wi * wny + tby) * 2];
-  d.jyb = tile_jy[((long long)wi * wny + tby) * 2 + 1];
-  d.pad[0] = d.pad[1] = 0;
+  // The descriptor is assembled in its slot of the list; the bitmaps are kept in
+  // named registers (static word indices) so that nothing lives in scratch.
+  WinDesc* D = &list[slot];
+  unsigned long long occ[FLAG_MAX / 64], rowm[4];
 #pragma unroll
-  for (int q = 0; q < FLAG_MAX / 64; ++q) d.occ[q] = 0ull;
+  for (int q = 0; q < FLAG_MAX / 64; ++q) occ[q] = 0ull;
 #pragma unroll
-  for (int q = 0; q < 4; ++q) d.rowmask[q] = 0ull;
-#pragma unroll
-  for (int q = 0; q < WIN_IDS; ++q) d.ids[q] = 0;
+  for (int q = 0; q < 4; ++q) rowm[q] = 0ull;
   const unsigned char* fl = flags + (long long)z * ftx * fty;
   int nocc = 0;
-  for (int fy = 0; fy < fny; ++fy) {
-    bool any = false;
-    for (int fx = 0; fx < fnx; ++fx) {
-      const int q = fy * fnx + fx;
-      if (fl[(long long)(fty0 + fy) * ftx + ftx0 + fx]) {
-        d.occ[q >> 6] |= 1ull << (q & 63);
-        if (nocc < WIN_IDS) d.ids[nocc] = (unsigned short)q;
-        ++nocc;
-        any = true;
-      }
+  auto lit_tile = [&](int fy, int q) {
+#pragma unroll
+    for (int wd = 0; wd < FLAG_MAX / 64; ++wd)
+      if ((q >> 6) == wd) occ[wd] |= 1ull << (q & 63);
+    if (nocc < WIN_IDS) D->ids[nocc] = (unsigned short)q;     // entries past nocc are never read
+    ++nocc;
+  };
+  auto lit_row = [&](int fy) {
+    const int r0 = max((fty0 + fy) * PT_Y - wy0, 0);
+    const int r1 = min((fty0 + fy + 1) * PT_Y - wy0, vrows);   // exclusive
+#pragma unroll
+    for (int wd = 0; wd < 4; ++wd) {
+      const int lo = max(r0 - 64 * wd, 0), hi = min(r1 - 64 * wd, 64);
+      if (lo < hi)
+        rowm[wd] |= (hi - lo == 64 ? ~0ull : ((1ull << (hi - lo)) - 1ull)) << lo;
     }
-    if (any) {
-      const int r0 = max((fty0 + fy) * PT_Y - wy0, 0);
-      const int r1 = min((fty0 + fy + 1) * PT_Y - wy0, vrows);   // exclusive
-      for (int r = r0; r < r1; ++r) d.rowmask[r >> 6] |= 1ull << (r & 63);
+  };
+  constexpr int CR = 16, CC = 8;      // rows x bytes per row requested together
+  if (fny <= CR && fnx <= CC) {
+    // every row's occupancy bytes in one 8-byte request (the buffer is padded
+    // for the over-read), all rows in flight together
+    unsigned long long rb[CR];
+#pragma unroll
+    for (int fy = 0; fy < CR; ++fy) {
+      rb[fy] = 0ull;
+      if (fy < fny) __builtin_memcpy(&rb[fy], fl + (long long)(fty0 + fy) * ftx + ftx0, 8);
+    }
+#pragma unroll
+    for (int fy = 0; fy < CR; ++fy) {
+      if (fy >= fny) continue;
+      bool any = false;
+#pragma unroll
+      for (int fx = 0; fx < CC; ++fx)
+        if (fx < fnx && ((rb[fy] >> (8 * fx)) & 0xffull)) { lit_tile(fy, fy * fnx + fx); any = true; }
+      if (any) lit_row(fy);
+    }
+  } else {
+    for (int fy = 0; fy < fny; ++fy) {
+      bool any = false;
+      for (int fx = 0; fx < fnx; ++fx)
+        if (fl[(long long)(fty0 + fy) * ftx + ftx0 + fx]) { lit_tile(fy, fy * fnx + fx); any = true; }
+      if (any) lit_row(fy);
     }
   }
-  d.nocc = nocc;
-  list[atomicAdd(count, 1)] = d;
+  D->e = e;
+  D->ixa = tile_ix[((long long)wi * wnx + tbx) * 2];
+  D->ixb = tile_ix[((long long)wi * wnx + tbx) * 2 + 1];
+  D->jya = tile_jy[((long long)wi * wny + tby) * 2];
+  D->jyb = tile_jy[((long long)wi * wny + tby) * 2 + 1];
+  D->nocc = nocc;
+  D->pad[0] = D->pad[1] = 0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) D->rowmask[q] = rowm[q];
+#pragma unroll
+  for (int q = 0; q < FLAG_MAX / 64; ++q) D->occ[q] = occ[q];
 }
 
 // k_conv_chi2: the hot-path form.  Persistent 512-thread workgroups walk the
@@ -2468,7 +2507,7 @@ int slamhip_create(const slamhip_desc* d, slamhip_ctx** out) {
   if ((rc = dev_alloc(c, &c->d_fracy, W * k.ny))) return rc;
   c->ftx = (n + PT_X - 1) / PT_X;
   c->fty = (n + PT_Y - 1) / PT_Y;
-  if ((rc = dev_alloc(c, &c->d_flags, W * k.nv * c->ftx * c->fty))) return rc;
+  if ((rc = dev_alloc(c, &c->d_flags, W * k.nv * c->ftx * c->fty + 8))) return rc;   // +8: k_compact reads rows 8 bytes at a time
   {
     // a conv window must not span more occupancy bytes than its LDS table holds
     const int ty = c->sep_variant == 2 ? 32 : 64;
