@@ -331,24 +331,32 @@ __device__ inline Surf surface_eval(const FitK& g, const WalkerK& w, int s,
 // 32x8 pixel tile as [sample rank][pixel] so k_profile's lanes (= pixels) read
 // consecutive 16-B entries for every rank.
 __global__ void __launch_bounds__(256)
-k_surface(FitK g, const WalkerK* __restrict__ wk, double2* __restrict__ geom) {
+k_surface(FitK g, const WalkerK* __restrict__ wk, double2* __restrict__ geom,
+          unsigned* __restrict__ gflag) {
   const long long leaf = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // slot
-  if (leaf >= g.nslot) return;
+  if (leaf >= g.nslot) return;                             // whole waves: nslot is a multiple of 256
   const int wi = blockIdx.z;
   const WalkerK& w = wk[wi];
   const unsigned code = g.leaf[leaf];
-  if (code == LEAF_PAD) {                                  // keeps k_profile's loads uniform
-    for (int s = 0; s < wk[blockIdx.z].nsurf; ++s)
-      geom[((long long)blockIdx.z * 4 + s) * g.nslot + leaf] = make_double2(VL_MASKED, 0.0);
-    return;
-  }
+  const bool pad = code == LEAF_PAD;                       // slot without a sample: an entry that adds nothing
   const int l = code >> 28, j = (code >> 14) & 0x3fff, i = code & 0x3fff;
-  const long long idx = ((long long)l * g.npix + j) * g.npix + i;
+  const long long idx = pad ? 0 : ((long long)l * g.npix + j) * g.npix + i;
   const double X0 = g.Xnest0[idx], Y0 = g.Ynest0[idx];
   const double X = X0 * w.cp - Y0 * w.sp;                  // utils.py:355
   const double Y = X0 * w.sp + Y0 * w.cp;                  // utils.py:356
-  const double lw = 1.0 / (double)(1 << (2 * l));          // avefour nesting :469-471
+  const double lw = 1.0 / (double)(1 << (2 * (pad ? 0 : l)));   // avefour nesting :469-471
   double pXc = 0.0, pb = 0.0, prt = 0.0;                   // root '+' leaves these for root '-' (same h)
+  // Most of the sky is masked (r > Rc, r < Rin): a wave whose 64 entries of a
+  // surface all add nothing stores none of them and clears that surface's bit in
+  // the wave's flag word, which k_profile reads before it asks for the entries.
+  unsigned fm = 0;
+  // r = hypot(x, Y) >= |Y|: without an envelope a sample with |Y| > Rc is masked on
+  // every surface whatever x is (:443-447); a wave of such samples is done here
+  const bool beyond = !g.envelope && fabs(Y) > w.Rc * (1.0 + 1e-12);
+  if (__ballot(!pad && !beyond) == 0ull) {
+    if ((threadIdx.x & 63) == 0) gflag[(long long)wi * (g.nslot >> 6) + (leaf >> 6)] = 0u;
+    return;
+  }
   for (int s = 0; s < w.nsurf; ++s) {
     double xs;
     if (w.kind[s] == 3) {                                  // :392-405, as surface_x
@@ -364,24 +372,27 @@ k_surface(FitK g, const WalkerK* __restrict__ wk, double2* __restrict__ geom) {
       xs = surface_x(w, s, X, Y);
     }
     const double r = sqrt(fma(xs, xs, Y * Y));             // :433
-    if (surface_masked(g, w, r)) {                         // NaN vlos: most of the sky, skip the rest
-      geom[((long long)wi * 4 + s) * g.nslot + leaf] = make_double2(VL_MASKED, 0.0);
-      continue;
+    double vl = VL_MASKED, wt = 0.0;
+    if (!pad && !surface_masked(g, w, r)) {                // else NaN vlos: most of the sky
+      vl = surface_vlos(g, w, s, xs, Y, r) * w.sqrtM;      // :460
+      wt = (r < w.Rc ? 1.0 : w.Ienv) * w.inv_ienv1;        // :465
+      if (w.pI != 0.0) wt = wt * exp(-w.pI * log(r));      // r**(-pI), :466-467
+      wt = wt * (lw * w.wmul[s]);
+      if (!(vl == vl) || !(wt == wt)) {                    // NaN -> contributes 0 (:463,:468)
+        vl = VL_MASKED;
+        wt = 0.0;
+      } else {
+        if (fabs(vl) > VL_MASKED) vl = VL_MASKED;
+        if (fabs(wt) > 1.79769313486231570815e308)         // nan_to_num(inf) :468
+          wt = copysign(1.79769313486231570815e308, wt);
+      }
     }
-    double vl = surface_vlos(g, w, s, xs, Y, r) * w.sqrtM; // :460
-    double wt = (r < w.Rc ? 1.0 : w.Ienv) * w.inv_ienv1;   // :465
-    if (w.pI != 0.0) wt = wt * exp(-w.pI * log(r));        // r**(-pI), :466-467
-    wt = wt * (lw * w.wmul[s]);
-    if (!(vl == vl) || !(wt == wt)) {                      // NaN -> contributes 0 (:463,:468)
-      vl = VL_MASKED;
-      wt = 0.0;
-    } else {
-      if (fabs(vl) > VL_MASKED) vl = VL_MASKED;
-      if (fabs(wt) > 1.79769313486231570815e308)           // nan_to_num(inf) :468
-        wt = copysign(1.79769313486231570815e308, wt);
+    if (__ballot(wt != 0.0 && vl != VL_MASKED) != 0ull) {  // wave-uniform
+      geom[((long long)wi * 4 + s) * g.nslot + leaf] = make_double2(vl, wt);
+      fm |= 1u << s;
     }
-    geom[((long long)wi * 4 + s) * g.nslot + leaf] = make_double2(vl, wt);
   }
+  if ((threadIdx.x & 63) == 0) gflag[(long long)wi * (g.nslot >> 6) + (leaf >> 6)] = fm;
 }
 
 // Tap for parity tests: xdisk / vlos(Mstar=1) on the full nested grid.
@@ -437,7 +448,7 @@ __device__ inline unsigned wave_or(unsigned v) {
 template <bool FAST>
 __global__ void __launch_bounds__(256)
 k_profile(FitK g, const WalkerK* __restrict__ wk, const double2* __restrict__ geom,
-          double* __restrict__ iunif, unsigned char* __restrict__ flags, int ftx, int fty,
+          const unsigned* __restrict__ gflag, double* __restrict__ iunif, unsigned char* __restrict__ flags, int ftx, int fty,
           unsigned char* __restrict__ winflag, int wnx, int wny, int wsx, int wsy) {
   __shared__ double s_prof[PROF_LEN];
   __shared__ unsigned s_mask[4];
@@ -491,21 +502,30 @@ k_profile(FitK g, const WalkerK* __restrict__ wk, const double2* __restrict__ ge
     double tks[CH];
 #pragma unroll
     for (int c = 0; c < CH; ++c) tks[c] = FAST ? tkp[c] : 0.0;
+    // k_surface's flag word of this wave's 64 samples of a rank: bit s = surface s
+    // was stored (else every entry adds nothing and nothing is read).  Flags run
+    // two ranks ahead of the work, entries one.
+    const unsigned* gf = gflag + (long long)wi * (g.nslot >> 6) + (g.tile_goff[tile] >> 6) + (tid >> 6);
+    unsigned fcur = 0, fnxt = nl > 0 ? __builtin_amdgcn_readfirstlane(gf[0]) : 0u;
+    unsigned fnn = nl > 1 ? __builtin_amdgcn_readfirstlane(gf[4]) : 0u;
     double2 q[4], qn[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s)
-      qn[s] = (s < nsurf && nl > 0) ? gw[(long long)s * g.nslot] : make_double2(VL_MASKED, 0.0);
+      qn[s] = ((fnxt >> s) & 1u) ? gw[(long long)s * g.nslot] : make_double2(VL_MASKED, 0.0);
     for (int i = 0; i < nl; ++i) {
 #pragma unroll
       for (int s = 0; s < 4; ++s) q[s] = qn[s];
+      fcur = fnxt;
+      fnxt = fnn;
       if (i + 1 < nl) {                                   // next rank's loads fly during this one
+        fnn = i + 2 < nl ? __builtin_amdgcn_readfirstlane(gf[(i + 2) * 4]) : 0u;
 #pragma unroll
         for (int s = 0; s < 4; ++s)
-          qn[s] = s < nsurf ? gw[(long long)s * g.nslot + (i + 1) * 256] : make_double2(VL_MASKED, 0.0);
+          qn[s] = ((fnxt >> s) & 1u) ? gw[(long long)s * g.nslot + (i + 1) * 256] : make_double2(VL_MASKED, 0.0);
       }
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        if (s >= nsurf) continue;
+        if (!((fcur >> s) & 1u)) continue;                // surface absent, or nothing stored for this wave
         const double vl = q[s].x, wt = q[s].y;
         const double o = vl + voff;
         if (fabs(o - cmid) > hwc) continue;               // no channel of this block is lit
@@ -1795,6 +1815,7 @@ struct slamhip_ctx {
   WalkerK* d_wk = nullptr;
   double* d_params = nullptr;
   double2* d_geom = nullptr;   // [walker][surface][sample] {vlos*sqrt(M), weight}
+  unsigned* d_gflag = nullptr; // [walker][sample / 64] bit s: surface s of these 64 samples was stored
   double* d_iunif = nullptr;
   double* d_iconv = nullptr;   // dense convolved cubes: one walker at create, grown on demand (dense mode only)
   int iconv_walkers = 0;
@@ -2067,18 +2088,18 @@ int run_model(slamhip_ctx* c, const double* d_params, int nw, hipStream_t st, bo
   {
     Timed t_(c, KID_SURFACE, st);
     dim3 g1((unsigned)((k.nslot + 255) / 256), 1, nw);
-    hipLaunchKernelGGL(k_surface, g1, dim3(256), 0, st, k, c->d_wk, c->d_geom);
+    hipLaunchKernelGGL(k_surface, g1, dim3(256), 0, st, k, c->d_wk, c->d_geom, c->d_gflag);
   }
   {
     Timed t_(c, KID_PROFILE, st);
     const int tgroups = (c->ftx * c->fty + 7) / 8;
     dim3 g2((unsigned)tgroups * 8u * (unsigned)(k.nvpad / CH) * (unsigned)nw, 1, 1);
     if (k.fast_idx)
-      hipLaunchKernelGGL(k_profile<true>, g2, dim3(256), 0, st, k, c->d_wk, c->d_geom,
+      hipLaunchKernelGGL(k_profile<true>, g2, dim3(256), 0, st, k, c->d_wk, c->d_geom, c->d_gflag,
                          c->d_iunif, c->d_flags, c->ftx, c->fty, c->d_winflag, (int)c->fz_grid.x, (int)c->fz_grid.y,
                          c->fz_sx, c->fz_sy);
     else
-      hipLaunchKernelGGL(k_profile<false>, g2, dim3(256), 0, st, k, c->d_wk, c->d_geom,
+      hipLaunchKernelGGL(k_profile<false>, g2, dim3(256), 0, st, k, c->d_wk, c->d_geom, c->d_gflag,
                          c->d_iunif, c->d_flags, c->ftx, c->fty, c->d_winflag, (int)c->fz_grid.x, (int)c->fz_grid.y,
                          c->fz_sx, c->fz_sy);
   }
@@ -2494,6 +2515,7 @@ int slamhip_create(const slamhip_desc* d, slamhip_ctx** out) {
   if ((rc = dev_alloc(c, &c->d_wk, W))) return rc;
   if ((rc = dev_alloc(c, &c->d_params, W * NP))) return rc;
   if ((rc = dev_alloc(c, &c->d_geom, W * 4 * k.nslot))) return rc;
+  if ((rc = dev_alloc(c, &c->d_gflag, W * (size_t)(k.nslot / 64)))) return rc;
   if ((rc = dev_alloc(c, &c->d_iunif, W * k.nv * n * n))) return rc;
   if ((rc = ensure_iconv(c, 1))) return rc;
   if (d->mom0decon && (rc = dev_alloc(c, &c->d_obs, W * ncube))) return rc;
