@@ -9,13 +9,18 @@
 //   chi2 :601-602
 // The design (sample list, kernels, HBM layout, rooflines) is in DESIGN.md.
 //
-// Pipeline per walker group (all fp64, HBM-resident intermediates):
-//   k_prep     : per-walker constants + 45-entry line-profile table
-//   k_surface  : deprojection + line-of-sight velocity per nested-grid sample
-//   k_profile  : line profile into velocity channels + nested-layer merge
-//   k_conv_sep / k_conv_2d : Gaussian beam convolution staged through LDS
-//   k_regrid   : bilinear regrid to observed pixels + fused sum(I*d), sum(I*I)
-//   k_finalize : fixed-order partial reduction -> scale, chi2
+// Pipeline per walker group (all fp64), scaling='uniform':
+//   k_prep      : per-walker constants, 45-entry line-profile table, regrid cells
+//   k_surface   : deprojection + line-of-sight velocity per nested-grid sample
+//   k_profile   : line profile into velocity channels + nested-layer merge ->
+//                 sparse Iunif (only 32x8 tiles with emission) + occupancy bytes
+//   k_compact   : list of conv windows that contain emission
+//   k_conv_chi2 : per window beam convolution in LDS (factorised beam or direct
+//                 taps), bilinear regrid to observed pixels, sum(I*d), sum(I*I)
+//   k_finalize  : fixed-order partial reduction -> scale, chi2
+// 'mom0*' scalings: k_prep/k_surface/k_profile, k_regrid_mom0, k_conv_obs_sep,
+// k_sum_chi2.  Dense single-vector products (cubemodel, parity taps):
+// k_conv_sep / k_conv_2d, k_regrid, k_scale, k_peak_unity.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
