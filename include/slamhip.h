@@ -68,7 +68,9 @@ typedef struct slamhip_desc {
   const double* v_valid;    /* [nv]                                 :270 */
   const double* data_valid; /* [nv][ny][nx]                         :274 */
   const double* gaussbeam;  /* [kbeam][kbeam], not normalised       :333 */
-  int64_t max_scratch_bytes; /* cap on per-batch device scratch; 0 = default */
+  int64_t max_scratch_bytes; /* cap on per-batch device scratch; 0 = default
+                              * (64 GB or 70 % of the free memory, at most
+                              * 128 walkers per launch group) */
   const double* mom0decon;  /* [ny][nx] deconvolved moment 0 for the 'mom0*'
                              * scalings (:343-364), NULL = scaling 'uniform'.
                              * With it, `gaussbeam` is the x-flipped kernel of
