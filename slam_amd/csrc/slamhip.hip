@@ -801,9 +801,9 @@ struct __attribute__((aligned(16))) WinDesc {
   int e;                         // window id: (walker*nv + channel)*wnx*wny + by*wnx + bx
   int ixa, ixb, jya, jyb;        // observed pixel ranges whose cells it owns
   int nocc;                      // occupied 32x8 input tiles under the window
-  int pad[2];
+  int z, tb;                     // plane walker*nv + channel; window column | row << 16 (spares the kernel's divisions)
   unsigned long long rowmask[4]; // window rows that hold emission
-  unsigned short ids[WIN_IDS];   // the first WIN_IDS occupied tiles (index fy*fnx+fx)
+  unsigned short ids[WIN_IDS];   // the first WIN_IDS occupied tiles (fy << 8 | fx)
   unsigned long long occ[FLAG_MAX / 64];   // all of them, as a bitmap
 };
 
@@ -849,7 +849,7 @@ k_compact(FitK g, const unsigned char* __restrict__ winflag, int total,
 #pragma unroll
     for (int wd = 0; wd < FLAG_MAX / 64; ++wd)
       if ((q >> 6) == wd) occ[wd] |= 1ull << (q & 63);
-    if (nocc < WIN_IDS) D->ids[nocc] = (unsigned short)q;     // entries past nocc are never read
+    if (nocc < WIN_IDS) D->ids[nocc] = (unsigned short)((fy << 8) | (q - fy * fnx));   // entries past nocc are never read
     ++nocc;
   };
   auto lit_row = [&](int fy) {
@@ -895,7 +895,8 @@ k_compact(FitK g, const unsigned char* __restrict__ winflag, int total,
   D->jya = tile_jy[((long long)wi * wny + tby) * 2];
   D->jyb = tile_jy[((long long)wi * wny + tby) * 2 + 1];
   D->nocc = nocc;
-  D->pad[0] = D->pad[1] = 0;
+  D->z = z;
+  D->tb = tbx | (tby << 16);
 #pragma unroll
   for (int q = 0; q < 4; ++q) D->rowmask[q] = rowm[q];
 #pragma unroll
@@ -978,8 +979,9 @@ k_conv_chi2(FitK g, const double* __restrict__ iunif,
     if (tid == 0 && nxt < nlive) fut = (int)gridDim.x + atomicAdd(queue, 1);
     const WinDesc* cur = reinterpret_cast<const WinDesc*>(&s_desc[par][0]);   // in LDS
     const int e = __builtin_amdgcn_readfirstlane(cur->e);   // descriptor fields are block-uniform: keep them scalar
-    const int z = e / (wnx * wny), tl = e - z * (wnx * wny);
-    const int tby = tl / wnx, tbx = tl - tby * wnx;
+    const int z = __builtin_amdgcn_readfirstlane(cur->z);
+    const int tb = __builtin_amdgcn_readfirstlane(cur->tb);
+    const int tby = tb >> 16, tbx = tb & 0xffff;
     const int wi = z / g.nv, k = z - wi * g.nv;
     const double* src = iunif + (long long)z * n * n;
     const int x0 = tbx * (TX - 1), y0 = tby * (TY - 1);
@@ -998,8 +1000,8 @@ k_conv_chi2(FitK g, const double* __restrict__ iunif,
       scc[u] = 0;
       sv[u][0] = sv[u][1] = sv[u][2] = sv[u][3] = 0.0;
       if (bq < nocc && bq < WIN_IDS) {
-        const int q = cur->ids[bq];
-        const int fyy = q / fnx, fxx = q - fyy * fnx;
+        const int q = __builtin_amdgcn_readfirstlane((int)cur->ids[bq]);   // wave-uniform
+        const int fyy = q >> 8, fxx = q & 255;
         const int gy = (fty0 + fyy) * PT_Y + (lane >> 3);
         const int gx0 = (ftx0 + fxx) * PT_X + (lane & 7) * 4;
         const int rr = gy - wy0;
@@ -2539,7 +2541,7 @@ int slamhip_create(const slamhip_desc* d, slamhip_ctx** out) {
     // a conv window must not span more occupancy bytes than its LDS table holds
     const int ty = c->sep_variant == 2 ? 32 : 64;
     const int spanx = (CONV_TX + K - 2) / PT_X + 2, spany = (ty + K - 2) / PT_Y + 2;
-    if (c->fused && spanx * spany > FLAG_MAX) c->fused = 0;
+    if (c->fused && (spanx * spany > FLAG_MAX || spanx > 255 || spany > 255)) c->fused = 0;   // descriptor ids pack (fy, fx) in 8 bits each
     if ((int)(c->fz_grid.x + c->fz_grid.y) > PREP_TILES) c->fused = 0;
   }
   {
