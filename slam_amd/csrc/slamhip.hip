@@ -511,8 +511,10 @@ k_profile(FitK g, const WalkerK* __restrict__ wk, const double2* __restrict__ ge
     // was stored (else every entry adds nothing and nothing is read).  Flags run
     // two ranks ahead of the work, entries one.
     const unsigned* gf = gflag + (long long)wi * (g.nslot >> 6) + (g.tile_goff[tile] >> 6) + (tid >> 6);
+    // (the word for rank i+2 stays in a VGPR until it is needed: moving it to
+    // an SGPR at once would wait for the load)
     unsigned fcur = 0, fnxt = nl > 0 ? __builtin_amdgcn_readfirstlane(gf[0]) : 0u;
-    unsigned fnn = nl > 1 ? __builtin_amdgcn_readfirstlane(gf[4]) : 0u;
+    unsigned fnn = nl > 1 ? gf[4] : 0u;
     double2 q[4], qn[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s)
@@ -521,9 +523,9 @@ k_profile(FitK g, const WalkerK* __restrict__ wk, const double2* __restrict__ ge
 #pragma unroll
       for (int s = 0; s < 4; ++s) q[s] = qn[s];
       fcur = fnxt;
-      fnxt = fnn;
+      fnxt = __builtin_amdgcn_readfirstlane(fnn);
       if (i + 1 < nl) {                                   // next rank's loads fly during this one
-        fnn = i + 2 < nl ? __builtin_amdgcn_readfirstlane(gf[(i + 2) * 4]) : 0u;
+        fnn = i + 2 < nl ? gf[(i + 2) * 4] : 0u;
 #pragma unroll
         for (int s = 0; s < 4; ++s)
           qn[s] = ((fnxt >> s) & 1u) ? gw[(long long)s * g.nslot + (i + 1) * 256] : make_double2(VL_MASKED, 0.0);
