@@ -485,6 +485,11 @@ k_profile(FitK g, const WalkerK* __restrict__ wk, const double2* __restrict__ ge
   const double2* gw = geom + (long long)wi * 4 * g.nslot + g.tile_goff[tile] + tid;
   const long long ftile = ntile;
   unsigned char* fl = flags + (long long)wi * g.nv * ftile + tile;
+  // k_surface's flag word of this wave's 64 samples of a rank: bit s = surface s
+  // was stored (else every entry adds nothing and nothing is read).  The first
+  // two are requested here, under the table's round trip.
+  const unsigned* gf = gflag + (long long)wi * (g.nslot >> 6) + (g.tile_goff[tile] >> 6) + (tid >> 6);
+  const unsigned f0v = nl > 0 ? gf[0] : 0u, f1v = nl > 1 ? gf[4] : 0u;
 
   __syncthreads();                                        // s_prof ready
   {
@@ -507,14 +512,11 @@ k_profile(FitK g, const WalkerK* __restrict__ wk, const double2* __restrict__ ge
     double tks[CH];
 #pragma unroll
     for (int c = 0; c < CH; ++c) tks[c] = FAST ? tkp[c] : 0.0;
-    // k_surface's flag word of this wave's 64 samples of a rank: bit s = surface s
-    // was stored (else every entry adds nothing and nothing is read).  Flags run
-    // two ranks ahead of the work, entries one.
-    const unsigned* gf = gflag + (long long)wi * (g.nslot >> 6) + (g.tile_goff[tile] >> 6) + (tid >> 6);
-    // (the word for rank i+2 stays in a VGPR until it is needed: moving it to
-    // an SGPR at once would wait for the load)
-    unsigned fcur = 0, fnxt = nl > 0 ? __builtin_amdgcn_readfirstlane(gf[0]) : 0u;
-    unsigned fnn = nl > 1 ? gf[4] : 0u;
+    // Flags run two ranks ahead of the work, entries one (the word for rank i+2
+    // stays in a VGPR until it is needed: moving it to an SGPR at once would
+    // wait for the load).
+    unsigned fcur = 0, fnxt = __builtin_amdgcn_readfirstlane(f0v);
+    unsigned fnn = f1v;
     double2 q[4], qn[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s)
