@@ -329,7 +329,9 @@ __device__ inline Surf surface_eval(const FitK& g, const WalkerK& w, int s,
   return o;
 }
 
-// k_surface: thread per (walker, surviving sample).  Writes, per live surface,
+constexpr int SURF_WPT = 8;   // walkers per k_surface thread
+
+// k_surface: thread per (SURF_WPT walkers, surviving sample).  Writes, per live surface,
 //   vl = vlos*sqrt(Mstar)          (1e300 where the reference has NaN)
 //   wt = intensity weight * layer-merge weight 4^-layer
 // as one {vl, wt} pair laid out [walker][surface][slot]; slots are ordered per
@@ -337,16 +339,17 @@ __device__ inline Surf surface_eval(const FitK& g, const WalkerK& w, int s,
 // consecutive 16-B entries for every rank.
 __global__ void __launch_bounds__(256)
 k_surface(FitK g, const WalkerK* __restrict__ wk, double2* __restrict__ geom,
-          unsigned* __restrict__ gflag) {
+          unsigned* __restrict__ gflag, int nw) {
   const long long leaf = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // slot
   if (leaf >= g.nslot) return;                             // whole waves: nslot is a multiple of 256
-  const int wi = blockIdx.z;
-  const WalkerK& w = wk[wi];
   const unsigned code = g.leaf[leaf];
   const bool pad = code == LEAF_PAD;                       // slot without a sample: an entry that adds nothing
   const int l = code >> 28, j = (code >> 14) & 0x3fff, i = code & 0x3fff;
   const long long idx = pad ? 0 : ((long long)l * g.npix + j) * g.npix + i;
   const double X0 = g.Xnest0[idx], Y0 = g.Ynest0[idx];
+  // the sample's coordinates serve SURF_WPT walkers
+  for (int wi = blockIdx.z * SURF_WPT, we = min(wi + SURF_WPT, nw); wi < we; ++wi) {
+  const WalkerK& w = wk[wi];
   const double X = X0 * w.cp - Y0 * w.sp;                  // utils.py:355
   const double Y = X0 * w.sp + Y0 * w.cp;                  // utils.py:356
   const double lw = 1.0 / (double)(1 << (2 * (pad ? 0 : l)));   // avefour nesting :469-471
@@ -360,7 +363,7 @@ k_surface(FitK g, const WalkerK* __restrict__ wk, double2* __restrict__ geom,
   const bool beyond = !g.envelope && fabs(Y) > w.Rc * (1.0 + 1e-12);
   if (__ballot(!pad && !beyond) == 0ull) {
     if ((threadIdx.x & 63) == 0) gflag[(long long)wi * (g.nslot >> 6) + (leaf >> 6)] = 0u;
-    return;
+    continue;
   }
   for (int s = 0; s < w.nsurf; ++s) {
     double xs;
@@ -398,6 +401,7 @@ k_surface(FitK g, const WalkerK* __restrict__ wk, double2* __restrict__ geom,
     }
   }
   if ((threadIdx.x & 63) == 0) gflag[(long long)wi * (g.nslot >> 6) + (leaf >> 6)] = fm;
+  }
 }
 
 // Tap for parity tests: xdisk / vlos(Mstar=1) on the full nested grid.
@@ -2098,8 +2102,8 @@ int run_model(slamhip_ctx* c, const double* d_params, int nw, hipStream_t st, bo
   }
   {
     Timed t_(c, KID_SURFACE, st);
-    dim3 g1((unsigned)((k.nslot + 255) / 256), 1, nw);
-    hipLaunchKernelGGL(k_surface, g1, dim3(256), 0, st, k, c->d_wk, c->d_geom, c->d_gflag);
+    dim3 g1((unsigned)((k.nslot + 255) / 256), 1, (nw + SURF_WPT - 1) / SURF_WPT);
+    hipLaunchKernelGGL(k_surface, g1, dim3(256), 0, st, k, c->d_wk, c->d_geom, c->d_gflag, nw);
   }
   {
     Timed t_(c, KID_PROFILE, st);
