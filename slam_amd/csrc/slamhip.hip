@@ -109,6 +109,7 @@ struct WalkerK {
   double h2[4];                  // h^2
   double hfac[4];                // (1+h^2)^(-3/4)                    :435
   double qa[4];                  // tan^-2 i - h^2                    :393
+  double iqa[4];                 // 1 / qa (the roots multiply by it: <= 1 ulp from the division of :405,:408)
   double qk[4];                  // tan^2 i - h^2                     :395
   double wmul[4];                // 2 for the doubled thin surface    :389-390
   double prof[PROF_LEN];
@@ -265,6 +266,7 @@ __global__ void k_prep(FitK g, const double* __restrict__ params, int nw,
       } else {                                   // :400-408
         for (int r = 0; r < 2; ++r) {
           o.kind[ns] = 3 + r; o.h2[ns] = hh; o.hfac[ns] = hf; o.qa[ns] = a;
+          o.iqa[ns] = 1.0 / a;
           o.qk[ns] = kq; o.wmul[ns] = 1.0;
           slot[r] = ns++;
         }
@@ -292,7 +294,7 @@ __device__ inline double surface_x(const WalkerK& w, int s, double X, double Y) 
   const double D = b * b - a * c;                          // :403
   if (!(D >= 0)) return __builtin_nan("");
   const double rt = sqrt(D);
-  return Xc + (kind == 3 ? (b + rt) : (b - rt)) / a;       // :405-408
+  return Xc + (kind == 3 ? (b + rt) : (b - rt)) * w.iqa[s];   // :405-408
 }
 
 // True where getvlos (:443-447) leaves NaN whatever the velocity is.
@@ -305,17 +307,26 @@ __device__ inline bool surface_masked(const FitK& g, const WalkerK& w, double r)
 __device__ inline double surface_vlos(const FitK& g, const WalkerK& w, int s,
                                       double x, double Y, double r) {
   const bool outer = r > w.Rc;                             // :434
-  const double rmh = 1.0 / sqrt(r);                        // r**(-1/2)
+  // r**(-1/2) from the hardware estimate and two Newton steps (r is a finite, normal
+  // radius here: masked and NaN samples never arrive), 1/r as its square: <= 3 ulp,
+  // a third of the instructions of a square root and two divisions
+  double rmh = __builtin_amdgcn_rsq(r);
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const double e = fma(-(r * rmh), rmh, 1.0);
+    rmh = fma(0.5 * rmh, e, rmh);
+  }
+  const double ir = rmh * rmh;
   double vp = rmh * w.hfac[s];                             // :435
   double vr = r * 0.0;                                     // :436
   if (g.envelope && outer) {
-    vp = sqrt(w.Rc) / r;                                   // :438
-    vr = -rmh * sqrt(2.0 - w.Rc / r);                      // :439
+    vp = sqrt(w.Rc) * ir;                                  // :438
+    vr = -rmh * sqrt(2.0 - w.Rc * ir);                     // :439
   }
-  const double erot = Y * g.signmajor / r;                 // :440
+  const double erot = Y * g.signmajor * ir;                // :440
   if (!(g.envelope && outer))                              // vr = 0: vr*erad adds (+-)0 for the finite r > 0 that get here
     return (vp * erot + vr) * w.sini * g.vunit;
-  const double erad = x * g.signminor / r;                 // :441
+  const double erad = x * g.signminor * ir;                // :441
   return (vp * erot + vr * erad) * w.sini * g.vunit;       // :442
 }
 
@@ -373,9 +384,9 @@ k_surface(FitK g, const WalkerK* __restrict__ wk, double2* __restrict__ geom,
       const double c = w.qk[s] * (pXc * pXc) - w.h2[s] * (Y * Y);
       const double D = pb * pb - w.qa[s] * c;
       prt = D >= 0 ? sqrt(D) : __builtin_nan("");
-      xs = pXc + (pb + prt) / w.qa[s];
+      xs = pXc + (pb + prt) * w.iqa[s];
     } else if (w.kind[s] == 4) {                           // :408, always right after its root '+'
-      xs = pXc + (pb - prt) / w.qa[s];
+      xs = pXc + (pb - prt) * w.iqa[s];
     } else {
       xs = surface_x(w, s, X, Y);
     }
