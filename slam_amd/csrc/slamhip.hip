@@ -1505,6 +1505,22 @@ k_finalize(FitK g, const double* __restrict__ partial, int nblk,
 // pixel's spectrum is rescaled so that its moment 0 equals the deconvolved
 // observed one, and the beam is applied on the observed grid.
 // ---------------------------------------------------------------------------
+// k_tile_krange: per (walker, Iunif tile) the channel range [lo, hi) in which
+// k_profile lit the tile (lo = nv, hi = 0 for a tile that stayed dark), so that
+// k_regrid_mom0 visits only channels that can hold emission under a pixel.
+__global__ void __launch_bounds__(256)
+k_tile_krange(FitK g, const unsigned char* __restrict__ flags, int ntile,
+              int2* __restrict__ krange) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= ntile) return;
+  const int wi = blockIdx.y;
+  const unsigned char* f = flags + (long long)wi * g.nv * ntile + t;
+  int lo = g.nv, hi = 0;
+  for (int k = 0; k < g.nv; ++k)
+    if (f[(long long)k * ntile]) { lo = min(lo, k); hi = k + 1; }
+  krange[(long long)wi * ntile + t] = make_int2(lo, hi);
+}
+
 // k_regrid_mom0: regrid (:475-483) and per-pixel moment-0 scale (:521-525) in
 // one pass.  Thread per (walker, observed pixel): the bilinear value of every
 // channel is formed twice (once for the moment, once for the scaled output)
@@ -1515,7 +1531,7 @@ __global__ void __launch_bounds__(256)
 k_regrid_mom0(FitK g, const int* __restrict__ cellx, const double* __restrict__ fracx,
               const int* __restrict__ celly, const double* __restrict__ fracy,
               const double* __restrict__ iunif, const unsigned char* __restrict__ flags,
-              int ftx, int fty, double* __restrict__ cube,
+              const int2* __restrict__ krange, int ftx, int fty, double* __restrict__ cube,
               unsigned char* __restrict__ tileflag, int tile_ty, int ntx, int nty) {
   const long long npix = (long long)g.ny * g.nx;
   const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -1529,24 +1545,55 @@ k_regrid_mom0(FitK g, const int* __restrict__ cellx, const double* __restrict__ 
   const bool inside = i0 >= 0 && i1 >= 0;         // fill_value = 0 outside
   const long long ntile = (long long)ftx * fty;
   int ta = 0, tb = 0, tc = 0, td = 0;
+  // channels outside [klo, khi) are dark in all four tiles under the pixel: their
+  // value is exactly 0, which neither moves the moment nor needs its loads
+  int klo = g.nv, khi = 0;
   if (inside && !nanq) {
     ta = (i0 / PT_Y) * ftx + i1 / PT_X;       tb = (i0 / PT_Y) * ftx + (i1 + 1) / PT_X;
     tc = ((i0 + 1) / PT_Y) * ftx + i1 / PT_X; td = ((i0 + 1) / PT_Y) * ftx + (i1 + 1) / PT_X;
+    const int2* kr = krange + (long long)wi * ntile;
+    const int2 ra = kr[ta], rb = kr[tb], rc = kr[tc], rd = kr[td];
+    klo = min(min(ra.x, rb.x), min(rc.x, rd.x));
+    khi = max(max(ra.y, rb.y), max(rc.y, rd.y));
   }
-  auto value = [&](int k) -> double {
-    if (nanq) return __builtin_nan("");
-    if (!inside) return 0.0;
-    const unsigned char* f = flags + ((long long)wi * g.nv + k) * ntile;
-    const unsigned char fa = f[ta], fb = f[tb], fc = f[tc], fd = f[td];
-    if (!(fa | fb | fc | fd)) return 0.0;
-    const double* c = iunif + (((long long)wi * g.nv + k) * n + i0) * n + i1;
-    const double v00 = fa ? c[0] : 0.0, v01 = fb ? c[1] : 0.0;
-    const double v10 = fc ? c[n] : 0.0, v11 = fd ? c[n + 1] : 0.0;
-    return v00 * (1 - t0) * (1 - t1) + v01 * (1 - t0) * t1 +
-           v10 * t0 * (1 - t1) + v11 * t0 * t1;     // scipy _rgi.py:478-482, as k_regrid
+  // A NaN query point has a NaN moment and so a zero spectrum (:521-525), a point
+  // outside the grid a zero one: both leave [klo, khi) empty.
+  // Channels k0 .. k0+RG_U-1 at once (indices past the cube repeat its last
+  // channel; the caller drops them): all flag bytes, then all four corners of
+  // every channel whatever its flags say, so that one memory round trip serves
+  // RG_U channels; corners in unlit tiles hold old data and are dropped here.
+  constexpr int RG_U = 4;
+  auto values = [&](int k0, double* out) {
+    unsigned char fa[RG_U], fb[RG_U], fc[RG_U], fd[RG_U];
+    double l00[RG_U], l01[RG_U], l10[RG_U], l11[RG_U];
+#pragma unroll
+    for (int u = 0; u < RG_U; ++u) {
+      const int kk = min(k0 + u, g.nv - 1);
+      const unsigned char* f = flags + ((long long)wi * g.nv + kk) * ntile;
+      fa[u] = f[ta]; fb[u] = f[tb]; fc[u] = f[tc]; fd[u] = f[td];
+    }
+#pragma unroll
+    for (int u = 0; u < RG_U; ++u) {
+      const int kk = min(k0 + u, g.nv - 1);
+      const double* c = iunif + (((long long)wi * g.nv + kk) * n + i0) * n + i1;
+      l00[u] = c[0]; l01[u] = c[1]; l10[u] = c[n]; l11[u] = c[n + 1];
+    }
+#pragma unroll
+    for (int u = 0; u < RG_U; ++u) {
+      const double v00 = fa[u] ? l00[u] : 0.0, v01 = fb[u] ? l01[u] : 0.0;
+      const double v10 = fc[u] ? l10[u] : 0.0, v11 = fd[u] ? l11[u] : 0.0;
+      out[u] = v00 * (1 - t0) * (1 - t1) + v01 * (1 - t0) * t1 +
+               v10 * t0 * (1 - t1) + v11 * t0 * t1;   // scipy _rgi.py:478-482, as k_regrid
+    }
   };
   double m0 = 0.0;
-  for (int k = 0; k < g.nv; ++k) m0 += value(k);
+  for (int k0 = klo; k0 < khi; k0 += RG_U) {
+    double v[RG_U];
+    values(k0, v);
+#pragma unroll
+    for (int u = 0; u < RG_U; ++u)
+      if (k0 + u < khi) m0 += v[u];
+  }
   m0 = m0 * g.dv;
   if (m0 < 0.0) m0 = __builtin_nan("");
   double* c = cube + (long long)wi * g.nv * npix + p;
@@ -1558,14 +1605,23 @@ k_regrid_mom0(FitK g, const int* __restrict__ cellx, const double* __restrict__ 
       ? tileflag + (long long)wi * g.nv * ntx * nty + (jy / tile_ty) * ntx + ix / C2_TX : nullptr;
   const double dec = g.mom0decon[p];
   const double big = std::numeric_limits<double>::max();
-  for (int k = 0; k < g.nv; ++k) {
-    double v = value(k) * dec / m0;
-    if (v != v) v = 0.0;
-    else if (v > big) v = big;
-    else if (v < -big) v = -big;
-    c[(long long)k * npix] = v;
-    if (fl && v != 0.0) fl[(long long)k * ntx * nty] = 1;
+  for (int k = 0; k < klo; ++k) c[(long long)k * npix] = 0.0;
+  for (int k0 = klo; k0 < khi; k0 += RG_U) {
+    double vv[RG_U];
+    values(k0, vv);
+#pragma unroll
+    for (int u = 0; u < RG_U; ++u) {
+      const int k = k0 + u;
+      if (k >= khi) break;
+      double v = vv[u] * dec / m0;
+      if (v != v) v = 0.0;
+      else if (v > big) v = big;
+      else if (v < -big) v = -big;
+      c[(long long)k * npix] = v;
+      if (fl && v != 0.0) fl[(long long)k * ntx * nty] = 1;
+    }
   }
+  for (int k = max(khi, klo); k < g.nv; ++k) c[(long long)k * npix] = 0.0;
 }
 
 // k_conv_obs: zero-padded 'same' convolution with the K x K beam on the observed
@@ -1846,6 +1902,7 @@ struct slamhip_ctx {
   double* d_iconv = nullptr;   // dense convolved cubes: one walker at create, grown on demand (dense mode only)
   int iconv_walkers = 0;
   double* d_obs = nullptr;     // 'mom0*' scalings: [walker][nv][ny][nx] regridded cube
+  int2* d_krange = nullptr;    // 'mom0*' scalings: [walker][Iunif tile] lit channel range
   dim3 ob_grid{1, 1, 1};       // k_conv_obs grid for ONE walker (z = nv)
   int ob_blocks = 0;
   int ob_ty = 0;               // rows per k_conv_obs_sep tile (32 / 16), 0 = direct taps
@@ -2147,9 +2204,12 @@ int run_group_mom0(slamhip_ctx* c, const double* d_params, int nw, double* d_chi
     const bool flagged = c->ob_ty && c->conv_mode != 1 && convolving;
     if (flagged)
       HIP_TRY(c, hipMemsetAsync(c->d_obflag, 0, (size_t)nw * k.nv * c->ob_grid.x * c->ob_nty, st));
+    const int ntile = c->ftx * c->fty;
+    hipLaunchKernelGGL(k_tile_krange, dim3((ntile + 255) / 256, nw), dim3(256), 0, st, k, c->d_flags,
+                       ntile, c->d_krange);
     hipLaunchKernelGGL(k_regrid_mom0, dim3((unsigned)((npix + 255) / 256), nw), dim3(256), 0, st, k,
                        c->d_cellx, c->d_fracx, c->d_celly, c->d_fracy, c->d_iunif, c->d_flags,
-                       c->ftx, c->fty, c->d_obs, flagged ? c->d_obflag : (unsigned char*)nullptr,
+                       c->d_krange, c->ftx, c->fty, c->d_obs, flagged ? c->d_obflag : (unsigned char*)nullptr,
                        c->ob_ty ? c->ob_ty : 1, (int)c->ob_grid.x, c->ob_nty);
   }
   if (!convolving) {       // peaktounity on the observed grid (:531-532), single-vector product
@@ -2556,6 +2616,7 @@ int slamhip_create(const slamhip_desc* d, slamhip_ctx** out) {
   c->ftx = (n + PT_X - 1) / PT_X;
   c->fty = (n + PT_Y - 1) / PT_Y;
   if ((rc = dev_alloc(c, &c->d_flags, W * k.nv * c->ftx * c->fty + 8))) return rc;   // +8: k_compact reads rows 8 bytes at a time
+  if (d->mom0decon && (rc = dev_alloc(c, &c->d_krange, W * (size_t)c->ftx * c->fty))) return rc;
   {
     // a conv window must not span more occupancy bytes than its LDS table holds
     const int ty = c->sep_variant == 2 ? 32 : 64;
