@@ -1522,22 +1522,32 @@ k_tile_krange(FitK g, const unsigned char* __restrict__ flags, int ntile,
 }
 
 // k_regrid_mom0: regrid (:475-483) and per-pixel moment-0 scale (:521-525) in
-// one pass.  Thread per (walker, observed pixel): the bilinear value of every
-// channel is formed twice (once for the moment, once for the scaled output)
-// instead of storing the unscaled cube; Iunif tiles that k_profile left unlit
-// are never read (their occupancy byte is 0), so Iunif need not be cleared.
-// Also raises the occupancy byte of the pixel's k_conv_obs_sep tile.
+// one pass.  A wave is 64 neighbouring pixels of one observed row, a thread one
+// pixel: the bilinear value of every channel is formed twice (once for the
+// moment, once for the scaled output) instead of storing the unscaled cube;
+// Iunif tiles that k_profile left unlit are never used (their occupancy byte is
+// 0), so Iunif need not be cleared.  Raises the occupancy byte of the pixel's
+// k_conv_obs_sep tile.  With `rowflag` ([walker][channel][row][64-pixel segment]
+// bytes, cleared by the caller) a wave stores a channel only if one of its
+// pixels is non-zero there and marks the segment; k_conv_obs_sep reads nothing
+// from unmarked segments, so dark sky is neither written nor read.  Without it
+// every pixel of every channel is stored.
 __global__ void __launch_bounds__(256)
 k_regrid_mom0(FitK g, const int* __restrict__ cellx, const double* __restrict__ fracx,
               const int* __restrict__ celly, const double* __restrict__ fracy,
               const double* __restrict__ iunif, const unsigned char* __restrict__ flags,
               const int2* __restrict__ krange, int ftx, int fty, double* __restrict__ cube,
-              unsigned char* __restrict__ tileflag, int tile_ty, int ntx, int nty) {
+              unsigned char* __restrict__ tileflag, int tile_ty, int ntx, int nty,
+              unsigned char* __restrict__ rowflag) {
   const long long npix = (long long)g.ny * g.nx;
-  const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (p >= npix) return;
-  const int wi = blockIdx.y;
-  const int jy = (int)(p / g.nx), ix = (int)(p - (long long)jy * g.nx);
+  const int lane = threadIdx.x & 63;
+  const int jy = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (jy >= g.ny) return;                          // whole waves
+  const int ixr = blockIdx.x * 64 + lane;
+  const bool valid = ixr < g.nx;
+  const int ix = valid ? ixr : g.nx - 1;
+  const long long p = (long long)jy * g.nx + ix;
+  const int wi = blockIdx.z;
   const int i1 = cellx[(long long)wi * g.nx + ix], i0 = celly[(long long)wi * g.ny + jy];
   const double t1 = fracx[(long long)wi * g.nx + ix], t0 = fracy[(long long)wi * g.ny + jy];
   const int n = g.nneed;
@@ -1548,7 +1558,8 @@ k_regrid_mom0(FitK g, const int* __restrict__ cellx, const double* __restrict__ 
   // channels outside [klo, khi) are dark in all four tiles under the pixel: their
   // value is exactly 0, which neither moves the moment nor needs its loads
   int klo = g.nv, khi = 0;
-  if (inside && !nanq) {
+  const bool query = inside && !nanq && valid;
+  if (query) {
     ta = (i0 / PT_Y) * ftx + i1 / PT_X;       tb = (i0 / PT_Y) * ftx + (i1 + 1) / PT_X;
     tc = ((i0 + 1) / PT_Y) * ftx + i1 / PT_X; td = ((i0 + 1) / PT_Y) * ftx + (i1 + 1) / PT_X;
     const int2* kr = krange + (long long)wi * ntile;
@@ -1556,6 +1567,7 @@ k_regrid_mom0(FitK g, const int* __restrict__ cellx, const double* __restrict__ 
     klo = min(min(ra.x, rb.x), min(rc.x, rd.x));
     khi = max(max(ra.y, rb.y), max(rc.y, rd.y));
   }
+  const int c0 = query ? i0 : 0, c1 = query ? i1 : 0;   // a cell every lane may read
   // A NaN query point has a NaN moment and so a zero spectrum (:521-525), a point
   // outside the grid a zero one: both leave [klo, khi) empty.
   // Channels k0 .. k0+RG_U-1 at once (indices past the cube repeat its last
@@ -1575,7 +1587,7 @@ k_regrid_mom0(FitK g, const int* __restrict__ cellx, const double* __restrict__ 
 #pragma unroll
     for (int u = 0; u < RG_U; ++u) {
       const int kk = min(k0 + u, g.nv - 1);
-      const double* c = iunif + (((long long)wi * g.nv + kk) * n + i0) * n + i1;
+      const double* c = iunif + (((long long)wi * g.nv + kk) * n + c0) * n + c1;
       l00[u] = c[0]; l01[u] = c[1]; l10[u] = c[n]; l11[u] = c[n + 1];
     }
 #pragma unroll
@@ -1596,32 +1608,49 @@ k_regrid_mom0(FitK g, const int* __restrict__ cellx, const double* __restrict__ 
   }
   m0 = m0 * g.dv;
   if (m0 < 0.0) m0 = __builtin_nan("");
-  double* c = cube + (long long)wi * g.nv * npix + p;
-  if (m0 == 0.0) {                                 // every channel is 0: 0*dec/0 -> NaN -> 0
-    for (int k = 0; k < g.nv; ++k) c[(long long)k * npix] = 0.0;
-    return;
+  // m0 == 0: every channel is 0 (0*dec/0 -> NaN -> 0): the pixel is dark
+  if (m0 == 0.0) { klo = g.nv; khi = 0; }
+  // the wave walks the union of its pixels' channel ranges
+  int wlo = klo, whi = khi;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    wlo = min(wlo, __shfl_xor(wlo, o));
+    whi = max(whi, __shfl_xor(whi, o));
   }
+  double* c = cube + (long long)wi * g.nv * npix + p;
   unsigned char* fl = tileflag
       ? tileflag + (long long)wi * g.nv * ntx * nty + (jy / tile_ty) * ntx + ix / C2_TX : nullptr;
+  unsigned char* rf = rowflag
+      ? rowflag + ((long long)wi * g.nv * g.ny + jy) * gridDim.x + blockIdx.x : nullptr;
   const double dec = g.mom0decon[p];
   const double big = std::numeric_limits<double>::max();
-  for (int k = 0; k < klo; ++k) c[(long long)k * npix] = 0.0;
-  for (int k0 = klo; k0 < khi; k0 += RG_U) {
+  if (!rf && valid) {
+    for (int k = 0; k < min(wlo, g.nv); ++k) c[(long long)k * npix] = 0.0;
+    for (int k = max(whi, wlo); k < g.nv; ++k) c[(long long)k * npix] = 0.0;
+  }
+  for (int k0 = wlo; k0 < whi; k0 += RG_U) {
     double vv[RG_U];
     values(k0, vv);
 #pragma unroll
     for (int u = 0; u < RG_U; ++u) {
       const int k = k0 + u;
-      if (k >= khi) break;
-      double v = vv[u] * dec / m0;
-      if (v != v) v = 0.0;
-      else if (v > big) v = big;
-      else if (v < -big) v = -big;
-      c[(long long)k * npix] = v;
-      if (fl && v != 0.0) fl[(long long)k * ntx * nty] = 1;
+      if (k >= whi) break;                         // wave-uniform
+      double v = 0.0;
+      if (k >= klo && k < khi) {
+        v = vv[u] * dec / m0;
+        if (v != v) v = 0.0;
+        else if (v > big) v = big;
+        else if (v < -big) v = -big;
+      }
+      const bool lit = v != 0.0;
+      if (rf) {
+        if (__ballot(lit) == 0ull) continue;       // nothing of this wave in channel k
+        if (lane == 0) rf[(long long)k * g.ny * gridDim.x] = 1;
+      }
+      if (valid) c[(long long)k * npix] = v;
+      if (fl && lit) fl[(long long)k * ntx * nty] = 1;
     }
   }
-  for (int k = max(khi, klo); k < g.nv; ++k) c[(long long)k * npix] = 0.0;
 }
 
 // k_conv_obs: zero-padded 'same' convolution with the K x K beam on the observed
@@ -1696,7 +1725,8 @@ __global__ void __launch_bounds__(256)
 k_conv_obs_sep(FitK g, const double* __restrict__ in, double* __restrict__ out,
                double* __restrict__ partial, int kpad, int nrank,
                const unsigned char* __restrict__ tileflag, const double* __restrict__ empty_ss,
-               const double* __restrict__ gxp, const double* __restrict__ gyp) {
+               const double* __restrict__ gxp, const double* __restrict__ gyp,
+               const unsigned char* __restrict__ rowflag) {
   extern __shared__ double lds[];
   constexpr int TX = C2_TX;
   const int K = g.kbeam, ng = g.ngauss, nx = g.nx, ny = g.ny;
@@ -1745,12 +1775,16 @@ k_conv_obs_sep(FitK g, const double* __restrict__ in, double* __restrict__ out,
   const double* src = in + (long long)blockIdx.z * plane;
   const int x0 = blockIdx.x * TX, y0 = blockIdx.y * TY;
   const int vrows = TY + K - 1, vcols = TX + K - 1;
+  // k_regrid_mom0 stored only the 64-pixel row segments it marked
+  const int nseg = (nx + 63) >> 6;
+  const unsigned char* rfl = rowflag ? rowflag + (long long)blockIdx.z * ny * nseg : nullptr;
   bool any = false;
   for (int e = tid; e < rows * P; e += 256) {
     const int rr = e / P, cc = e - rr * P;
     const int gy = y0 - ng + rr, gx = x0 - ng + cc;
     double v = 0.0;
-    if (rr < vrows && cc < vcols && gy >= 0 && gy < ny && gx >= 0 && gx < nx)
+    if (rr < vrows && cc < vcols && gy >= 0 && gy < ny && gx >= 0 && gx < nx &&
+        (!rfl || rfl[gy * nseg + (gx >> 6)]))
       v = src[(long long)gy * nx + gx];
     any |= v != 0.0;
     tile[e] = v;
@@ -1903,6 +1937,7 @@ struct slamhip_ctx {
   int iconv_walkers = 0;
   double* d_obs = nullptr;     // 'mom0*' scalings: [walker][nv][ny][nx] regridded cube
   int2* d_krange = nullptr;    // 'mom0*' scalings: [walker][Iunif tile] lit channel range
+  unsigned char* d_rowflag = nullptr;   // 'mom0*' scalings: [walker][nv][ny][nx/64] stored row segments
   dim3 ob_grid{1, 1, 1};       // k_conv_obs grid for ONE walker (z = nv)
   int ob_blocks = 0;
   int ob_ty = 0;               // rows per k_conv_obs_sep tile (32 / 16), 0 = direct taps
@@ -2207,10 +2242,14 @@ int run_group_mom0(slamhip_ctx* c, const double* d_params, int nw, double* d_chi
     const int ntile = c->ftx * c->fty;
     hipLaunchKernelGGL(k_tile_krange, dim3((ntile + 255) / 256, nw), dim3(256), 0, st, k, c->d_flags,
                        ntile, c->d_krange);
-    hipLaunchKernelGGL(k_regrid_mom0, dim3((unsigned)((npix + 255) / 256), nw), dim3(256), 0, st, k,
+    const int nseg = (k.nx + 63) / 64;
+    if (flagged)
+      HIP_TRY(c, hipMemsetAsync(c->d_rowflag, 0, (size_t)nw * k.nv * k.ny * nseg, st));
+    hipLaunchKernelGGL(k_regrid_mom0, dim3(nseg, (k.ny + 3) / 4, nw), dim3(256), 0, st, k,
                        c->d_cellx, c->d_fracx, c->d_celly, c->d_fracy, c->d_iunif, c->d_flags,
                        c->d_krange, c->ftx, c->fty, c->d_obs, flagged ? c->d_obflag : (unsigned char*)nullptr,
-                       c->ob_ty ? c->ob_ty : 1, (int)c->ob_grid.x, c->ob_nty);
+                       c->ob_ty ? c->ob_ty : 1, (int)c->ob_grid.x, c->ob_nty,
+                       flagged ? c->d_rowflag : (unsigned char*)nullptr);
   }
   if (!convolving) {       // peaktounity on the observed grid (:531-532), single-vector product
     hipLaunchKernelGGL(k_peak_unity, dim3(k.nv * nw), dim3(256), 0, st, k, c->d_obs, d_model,
@@ -2223,7 +2262,8 @@ int run_group_mom0(slamhip_ctx* c, const double* d_params, int nw, double* d_chi
     dim3 g(c->ob_grid.x, (k.ny + c->ob_ty - 1) / c->ob_ty, c->ob_grid.z * nw);
 #define SLAM_OBS(TY_, NIT_, WR_)                                                            \
     hipLaunchKernelGGL((k_conv_obs_sep<TY_, NIT_, WR_>), g, dim3(256), c->ob_lds, st, k, c->d_obs, \
-                       d_model, c->d_partial, c->kpad, c->nrank, c->d_obflag, c->d_obempty, k.gx_pad, k.gy_pad)
+                       d_model, c->d_partial, c->kpad, c->nrank, c->d_obflag, c->d_obempty, k.gx_pad, k.gy_pad, \
+                       c->d_rowflag)
     if (c->ob_ty == 32 && c->ob_nit == 2) { if (d_model) SLAM_OBS(32, 2, true); else SLAM_OBS(32, 2, false); }
     else if (c->ob_ty == 32)              { if (d_model) SLAM_OBS(32, 4, true); else SLAM_OBS(32, 4, false); }
     else                                  { if (d_model) SLAM_OBS(16, 4, true); else SLAM_OBS(16, 4, false); }
@@ -2617,6 +2657,7 @@ int slamhip_create(const slamhip_desc* d, slamhip_ctx** out) {
   c->fty = (n + PT_Y - 1) / PT_Y;
   if ((rc = dev_alloc(c, &c->d_flags, W * k.nv * c->ftx * c->fty + 8))) return rc;   // +8: k_compact reads rows 8 bytes at a time
   if (d->mom0decon && (rc = dev_alloc(c, &c->d_krange, W * (size_t)c->ftx * c->fty))) return rc;
+  if (d->mom0decon && (rc = dev_alloc(c, &c->d_rowflag, W * (size_t)k.nv * k.ny * ((k.nx + 63) / 64)))) return rc;
   {
     // a conv window must not span more occupancy bytes than its LDS table holds
     const int ty = c->sep_variant == 2 ? 32 : 64;
@@ -2651,7 +2692,8 @@ int slamhip_create(const slamhip_desc* d, slamhip_ctx** out) {
 #define SLAM_OBS0(TY_, NIT_)                                                                 \
     hipLaunchKernelGGL((k_conv_obs_sep<TY_, NIT_, false>), g, dim3(256), c->ob_lds, c->stream, k, \
                        c->d_obs, (double*)nullptr, c->d_obempty, c->kpad, c->nrank,          \
-                       (const unsigned char*)nullptr, (const double*)nullptr, k.gx_pad, k.gy_pad)
+                       (const unsigned char*)nullptr, (const double*)nullptr, k.gx_pad, k.gy_pad,  \
+                       (const unsigned char*)nullptr)
     if (c->ob_ty == 32 && c->ob_nit == 2) SLAM_OBS0(32, 2);
     else if (c->ob_ty == 32) SLAM_OBS0(32, 4);
     else SLAM_OBS0(16, 4);
