@@ -1721,12 +1721,13 @@ k_conv_obs(FitK g, const double* __restrict__ in, double* __restrict__ out,
 // leading singular triplets, tail < 1e-13, for a rotated one): per term a row
 // pass into an LDS intermediate and a column pass, 2K instead of K^2 taps.
 template <int TY, int NIT, bool WRITE>
-__global__ void __launch_bounds__(256)
-k_conv_obs_sep(FitK g, const double* __restrict__ in, double* __restrict__ out,
-               double* __restrict__ partial, int kpad, int nrank,
-               const unsigned char* __restrict__ tileflag, const double* __restrict__ empty_ss,
-               const double* __restrict__ gxp, const double* __restrict__ gyp,
-               const unsigned char* __restrict__ rowflag) {
+__device__ __forceinline__ void
+conv_obs_sep_window(const FitK& g, const double* __restrict__ in, double* __restrict__ out,
+                    double* __restrict__ partial, int kpad, int nrank,
+                    const unsigned char* __restrict__ tileflag, const double* __restrict__ empty_ss,
+                    const double* __restrict__ gxp, const double* __restrict__ gyp,
+                    const unsigned char* __restrict__ rowflag,
+                    const int bx, const int by, const int bz, const int ntx, const int nty) {
   extern __shared__ double lds[];
   constexpr int TX = C2_TX;
   const int K = g.kbeam, ng = g.ngauss, nx = g.nx, ny = g.ny;
@@ -1734,12 +1735,11 @@ k_conv_obs_sep(FitK g, const double* __restrict__ in, double* __restrict__ out,
     // no emission in any tile under this window's halo: the model is 0 here and
     // the residual sum is the tile's sum of data^2, computed once per fit by this
     // same kernel on an all-zero cube (`empty_ss`)
-    const int ntx = gridDim.x, nty = gridDim.y;
-    const int fx0 = max((int)blockIdx.x * TX - ng, 0) / TX;
-    const int fx1 = min((int)blockIdx.x * TX + TX - 1 + ng, nx - 1) / TX;
-    const int fy0 = max((int)blockIdx.y * TY - ng, 0) / TY;
-    const int fy1 = min((int)blockIdx.y * TY + TY - 1 + ng, ny - 1) / TY;
-    const unsigned char* fl = tileflag + (long long)blockIdx.z * ntx * nty;
+    const int fx0 = max(bx * TX - ng, 0) / TX;
+    const int fx1 = min(bx * TX + TX - 1 + ng, nx - 1) / TX;
+    const int fy0 = max(by * TY - ng, 0) / TY;
+    const int fy1 = min(by * TY + TY - 1 + ng, ny - 1) / TY;
+    const unsigned char* fl = tileflag + (long long)bz * ntx * nty;
     bool some = false;
     const int nf = (fx1 - fx0 + 1) * (fy1 - fy0 + 1);
     for (int e = threadIdx.x; e < nf; e += 256) {
@@ -1747,14 +1747,14 @@ k_conv_obs_sep(FitK g, const double* __restrict__ in, double* __restrict__ out,
       some |= fl[fy * ntx + fx] != 0;
     }
     if (!__syncthreads_or(some)) {
-      const long long blk1 = ((long long)(blockIdx.z % g.nv) * nty + blockIdx.y) * ntx + blockIdx.x;
-      const long long blk = ((long long)blockIdx.z * nty + blockIdx.y) * ntx + blockIdx.x;
+      const long long blk1 = ((long long)(bz % g.nv) * nty + by) * ntx + bx;
+      const long long blk = ((long long)bz * nty + by) * ntx + bx;
       if (threadIdx.x == 0) partial[blk] = empty_ss[blk1];
       if (WRITE) {
         const long long plane = (long long)ny * nx;
         for (int e = threadIdx.x; e < TX * TY; e += 256) {
-          const int gy = blockIdx.y * TY + e / TX, gx = blockIdx.x * TX + (e & (TX - 1));
-          if (gx < nx && gy < ny) out[(long long)blockIdx.z * plane + (long long)gy * nx + gx] = 0.0;
+          const int gy = by * TY + e / TX, gx = bx * TX + (e & (TX - 1));
+          if (gx < nx && gy < ny) out[(long long)bz * plane + (long long)gy * nx + gx] = 0.0;
         }
       }
       return;
@@ -1771,13 +1771,13 @@ k_conv_obs_sep(FitK g, const double* __restrict__ in, double* __restrict__ out,
   double* tmp = nrank > 1 ? lds + rows * P : lds;   // [rows][P2]; overlays the tile for one term
   const int tid = threadIdx.x;
   const long long plane = (long long)ny * nx;
-  const int k = blockIdx.z % g.nv;
-  const double* src = in + (long long)blockIdx.z * plane;
-  const int x0 = blockIdx.x * TX, y0 = blockIdx.y * TY;
+  const int k = bz % g.nv;
+  const double* src = in + (long long)bz * plane;
+  const int x0 = bx * TX, y0 = by * TY;
   const int vrows = TY + K - 1, vcols = TX + K - 1;
   // k_regrid_mom0 stored only the 64-pixel row segments it marked
   const int nseg = (nx + 63) >> 6;
-  const unsigned char* rfl = rowflag ? rowflag + (long long)blockIdx.z * ny * nseg : nullptr;
+  const unsigned char* rfl = rowflag ? rowflag + (long long)bz * ny * nseg : nullptr;
   bool any = false;
   for (int e = tid; e < rows * P; e += 256) {
     const int rr = e / P, cc = e - rr * P;
@@ -1865,7 +1865,7 @@ k_conv_obs_sep(FitK g, const double* __restrict__ in, double* __restrict__ out,
       const int gy = y0 + wv * R + r;
       if (gx < nx && gy < ny) {
         const long long e = (long long)gy * nx + gx;
-        if (WRITE) out[(long long)blockIdx.z * plane + e] = acc[r];
+        if (WRITE) out[(long long)bz * plane + e] = acc[r];
         const double d = g.data[(long long)k * plane + e] - acc[r];
         const double q = d * d;
         if (q == q) ss += q;
@@ -1877,8 +1877,76 @@ k_conv_obs_sep(FitK g, const double* __restrict__ in, double* __restrict__ out,
   if ((tid & 63) == 0) sred[tid >> 6] = ss;
   __syncthreads();
   if (tid == 0) {
-    const long long blk = ((long long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    const long long blk = ((long long)bz * nty + by) * ntx + bx;
     partial[blk] = (sred[0] + sred[1]) + (sred[2] + sred[3]);
+  }
+}
+
+template <int TY, int NIT, bool WRITE>
+__global__ void __launch_bounds__(256)
+k_conv_obs_sep(FitK g, const double* __restrict__ in, double* __restrict__ out,
+               double* __restrict__ partial, int kpad, int nrank,
+               const unsigned char* __restrict__ tileflag, const double* __restrict__ empty_ss,
+               const double* __restrict__ gxp, const double* __restrict__ gyp,
+               const unsigned char* __restrict__ rowflag) {
+  conv_obs_sep_window<TY, NIT, WRITE>(g, in, out, partial, kpad, nrank, tileflag, empty_ss, gxp, gyp,
+                                      rowflag, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, gridDim.y);
+}
+
+// k_obs_list: thread per (walker, channel, beam window).  A window with no
+// emission in any tile under its halo gets the tile's precomputed residual sum
+// (`empty_ss`, see k_conv_obs_sep); the others are appended to `list`
+// (count[0] = their number; order is arbitrary, results do not depend on it).
+__global__ void __launch_bounds__(256)
+k_obs_list(FitK g, const unsigned char* __restrict__ tileflag, const double* __restrict__ empty_ss,
+           double* __restrict__ partial, int* __restrict__ list, int* __restrict__ count,
+           int ntx, int nty, int TY, long long nwin) {
+  const long long blk = (long long)blockIdx.x * 256 + threadIdx.x;
+  bool live = false;
+  if (blk < nwin) {
+    const int bx = (int)(blk % ntx), by = (int)((blk / ntx) % nty);
+    const long long bz = blk / ((long long)ntx * nty);
+    const int ng = g.ngauss;
+    const int fx0 = max(bx * C2_TX - ng, 0) / C2_TX;
+    const int fx1 = min(bx * C2_TX + C2_TX - 1 + ng, g.nx - 1) / C2_TX;
+    const int fy0 = max(by * TY - ng, 0) / TY;
+    const int fy1 = min(by * TY + TY - 1 + ng, g.ny - 1) / TY;
+    const unsigned char* fl = tileflag + bz * ntx * nty;
+    for (int fy = fy0; fy <= fy1; ++fy)
+      for (int fx = fx0; fx <= fx1; ++fx) live |= fl[fy * ntx + fx] != 0;
+    if (!live) partial[blk] = empty_ss[((long long)(bz % g.nv) * nty + by) * ntx + bx];
+  }
+  const unsigned long long m = __ballot(live);
+  if (m) {
+    const int lane = threadIdx.x & 63;
+    const int leader = __ffsll((long long)m) - 1;
+    int base = 0;
+    if (lane == leader) base = atomicAdd(&count[0], __popcll(m));
+    base = __shfl(base, leader);
+    if (live) list[base + __popcll(m & ((1ull << lane) - 1ull))] = (int)blk;
+  }
+}
+
+// k_conv_obs_live: persistent workgroups take the listed windows by ticket
+// (count[1]) and run k_conv_obs_sep's window on each.
+template <int TY, int NIT>
+__global__ void __launch_bounds__(256)
+k_conv_obs_live(FitK g, const double* __restrict__ in, double* __restrict__ partial, int kpad,
+                int nrank, const double* __restrict__ gxp, const double* __restrict__ gyp,
+                const unsigned char* __restrict__ rowflag, const int* __restrict__ list,
+                int* __restrict__ count, int ntx, int nty) {
+  __shared__ int s_ticket;
+  const int nlive = count[0];
+  for (;;) {
+    if (threadIdx.x == 0) s_ticket = atomicAdd(&count[1], 1);
+    __syncthreads();
+    const int t = s_ticket;
+    if (t >= nlive) return;                        // every wave leaves here
+    const int blk = list[t];
+    const int bx = blk % ntx, by = (blk / ntx) % nty, bz = blk / (ntx * nty);
+    conv_obs_sep_window<TY, NIT, false>(g, in, nullptr, partial, kpad, nrank, nullptr, nullptr, gxp, gyp,
+                                        rowflag, bx, by, bz, ntx, nty);
+    __syncthreads();
   }
 }
 
@@ -1938,6 +2006,9 @@ struct slamhip_ctx {
   double* d_obs = nullptr;     // 'mom0*' scalings: [walker][nv][ny][nx] regridded cube
   int2* d_krange = nullptr;    // 'mom0*' scalings: [walker][Iunif tile] lit channel range
   unsigned char* d_rowflag = nullptr;   // 'mom0*' scalings: [walker][nv][ny][nx/64] stored row segments
+  int* d_oblist = nullptr;              // 'mom0*' scalings: beam windows with emission, count[2]
+  int* d_obcount = nullptr;
+  int ob_persist = 0;                   // workgroups of k_conv_obs_live
   dim3 ob_grid{1, 1, 1};       // k_conv_obs grid for ONE walker (z = nv)
   int ob_blocks = 0;
   int ob_ty = 0;               // rows per k_conv_obs_sep tile (32 / 16), 0 = direct taps
@@ -2260,6 +2331,22 @@ int run_group_mom0(slamhip_ctx* c, const double* d_params, int nw, double* d_chi
   if (c->ob_ty && c->conv_mode != 1) {
     Timed t_(c, KID_CONV, st);
     dim3 g(c->ob_grid.x, (k.ny + c->ob_ty - 1) / c->ob_ty, c->ob_grid.z * nw);
+    if (!d_model && c->d_oblist) {
+      // batch path: list the windows with emission, then persistent workgroups
+      const long long nwin = (long long)g.x * g.y * g.z;
+      HIP_TRY(c, hipMemsetAsync(c->d_obcount, 0, 2 * sizeof(int), st));
+      hipLaunchKernelGGL(k_obs_list, dim3((unsigned)((nwin + 255) / 256)), dim3(256), 0, st, k,
+                         c->d_obflag, c->d_obempty, c->d_partial, c->d_oblist, c->d_obcount,
+                         (int)g.x, (int)g.y, c->ob_ty, nwin);
+#define SLAM_OBL(TY_, NIT_)                                                                   \
+      hipLaunchKernelGGL((k_conv_obs_live<TY_, NIT_>), dim3(c->ob_persist), dim3(256), c->ob_lds, st, k, \
+                         c->d_obs, c->d_partial, c->kpad, c->nrank, k.gx_pad, k.gy_pad, c->d_rowflag, \
+                         c->d_oblist, c->d_obcount, (int)g.x, (int)g.y)
+      if (c->ob_ty == 32 && c->ob_nit == 2) SLAM_OBL(32, 2);
+      else if (c->ob_ty == 32) SLAM_OBL(32, 4);
+      else SLAM_OBL(16, 4);
+#undef SLAM_OBL
+    } else {
 #define SLAM_OBS(TY_, NIT_, WR_)                                                            \
     hipLaunchKernelGGL((k_conv_obs_sep<TY_, NIT_, WR_>), g, dim3(256), c->ob_lds, st, k, c->d_obs, \
                        d_model, c->d_partial, c->kpad, c->nrank, c->d_obflag, c->d_obempty, k.gx_pad, k.gy_pad, \
@@ -2268,6 +2355,7 @@ int run_group_mom0(slamhip_ctx* c, const double* d_params, int nw, double* d_chi
     else if (c->ob_ty == 32)              { if (d_model) SLAM_OBS(32, 4, true); else SLAM_OBS(32, 4, false); }
     else                                  { if (d_model) SLAM_OBS(16, 4, true); else SLAM_OBS(16, 4, false); }
 #undef SLAM_OBS
+    }
     const int nblk = (int)(g.x * g.y) * k.nv;
     Timed t2_(c, KID_FINALIZE, st);
     hipLaunchKernelGGL(k_sum_chi2, dim3(nw), dim3(256), 0, st, k, c->d_partial, nblk,
@@ -2631,6 +2719,10 @@ int slamhip_create(const slamhip_desc* d, slamhip_ctx** out) {
                                       : (const void*)k_conv_obs_sep<16, 4, false>;
       HIP_TRY(c, hipFuncSetAttribute(fw, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->ob_lds));
       HIP_TRY(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->ob_lds));
+      const void* fl = c->ob_ty == 32 ? (c->ob_nit == 2 ? (const void*)k_conv_obs_live<32, 2>
+                                                        : (const void*)k_conv_obs_live<32, 4>)
+                                      : (const void*)k_conv_obs_live<16, 4>;
+      HIP_TRY(c, hipFuncSetAttribute(fl, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->ob_lds));
     }
   }
   c->ob_grid = dim3((k.nx + C2_TX - 1) / C2_TX, (k.ny + C2_TY - 1) / C2_TY, k.nv);
@@ -2687,6 +2779,14 @@ int slamhip_create(const slamhip_desc* d, slamhip_ctx** out) {
     const size_t ntile = (size_t)c->ob_grid.x * c->ob_nty;
     if ((rc = dev_alloc(c, &c->d_obflag, W * k.nv * ntile))) return rc;
     if ((rc = dev_alloc(c, &c->d_obempty, (size_t)k.nv * ntile))) return rc;
+    if (W * k.nv * ntile < (size_t)1 << 31) {     // window ids are ints
+      if ((rc = dev_alloc(c, &c->d_oblist, W * k.nv * ntile))) return rc;
+      if ((rc = dev_alloc(c, &c->d_obcount, 64))) return rc;
+      hipDeviceProp_t pr;
+      HIP_TRY(c, hipGetDeviceProperties(&pr, c->device));
+      const int per = std::max(1, std::min(8, (int)((160 * 1024) / (c->ob_lds + 1024))));
+      c->ob_persist = pr.multiProcessorCount * per;
+    }
     HIP_TRY(c, hipMemsetAsync(c->d_obs, 0, ncube * sizeof(double), c->stream));
     dim3 g(c->ob_grid.x, c->ob_nty, k.nv);
 #define SLAM_OBS0(TY_, NIT_)                                                                 \
