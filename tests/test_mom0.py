@@ -130,3 +130,37 @@ def test_gpu_mom0_fitting_runs(tmp_path):
     lnp = fit.lnprob(np.array([np.log10(p[0]), np.log10(p[1]), p[3], p[4], p[5]]))
     assert lnp == pytest.approx(-0.5 * float(m['mom0ft_vec_generic_chi2']), rel=1e-9)
     assert os.path.exists(tmp_path / 'f.popt.txt')
+
+
+@pytest.mark.gpu
+def test_gpu_sparse_path_equals_dense_on_a_multi_segment_image():
+    """200 x 200 pixels = 4 row segments of 64 (the last one partial), several beam
+    windows per plane: the batch path (lit channel ranges, row segments stored only
+    where they hold emission, listed windows taken by persistent workgroups) against
+    the dense direct-tap path (conv mode 1: every pixel stored, every window run),
+    with offsets that push part of the image outside the model grid, and with what
+    earlier batches left in the scratch cube."""
+    from slam_amd import synth
+    fit = synth.make_fit(None, N=200, NV=12, beam_px=(6, 4), scaling='mom0ft')
+    try:
+        P = synth.walkers(7)
+        P[1, 8], P[1, 9] = 35.0, -20.0          # xoff, yoff [au]
+        P[2, 8], P[2, 9] = -150.0, 120.0
+        P[3, 10] = 0.3                          # voff
+        P[4, 1] = 400.0                         # disk larger than the image
+        chi2 = fit.chi2_batch(P)
+        assert np.all(np.isfinite(chi2)) and len(set(chi2.tolist())) == len(P)
+        # other walkers' cubes are in the scratch slots now: order and split, bitwise
+        assert np.array_equal(fit.chi2_batch(P[::-1])[::-1], chi2)
+        assert np.array_equal(np.array([fit.chi2_batch(p[None])[0] for p in P]), chi2)
+        assert np.array_equal(fit.chi2_batch(P[2:5]), chi2[2:5])
+        fit.engine.set_conv_mode(1)
+        dense = fit.chi2_batch(P)
+        fit.engine.set_conv_mode(0)
+        np.testing.assert_allclose(chi2, dense, rtol=1e-11)
+        # single-vector product (one workgroup per window, writes the cube) agrees too
+        for i in (0, 2):
+            _, st = fit.engine.cubemodel(P[i], return_stats=True)
+            assert st['chi2'] == pytest.approx(chi2[i], rel=1e-12)
+    finally:
+        fit.close()
