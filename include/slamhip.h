@@ -95,7 +95,13 @@ int slamhip_chi2_batch(slamhip_ctx* ctx, const double* params, int nw,
 
 /* Same, with `params_dev` [nw][13] and `chi2_dev` [nw] already resident in
  * device memory on the context's GPU.  Work is enqueued on `stream` (a
- * hipStream_t passed as void*, NULL = default stream) and NOT waited for. */
+ * hipStream_t passed as void*, NULL = default stream) and NOT waited for; the
+ * call allocates nothing.
+ * Ordering: every entry point of one context works in that context's single
+ * scratch set.  The library orders them on the device -- a call on another
+ * stream than the previous one first waits (hipStreamWaitEvent) for the
+ * previous call's last kernel -- but the HOST calls on one context must not
+ * overlap: one thread at a time per context. */
 int slamhip_chi2_batch_dev(slamhip_ctx* ctx, const double* params_dev, int nw,
                            double* chi2_dev, void* stream);
 

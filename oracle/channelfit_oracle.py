@@ -300,8 +300,18 @@ def avefour(a):
 
 
 def iunif(setup, xs_list, vlos_list, Ynest, prof, prof_n, prof_d,
-          Mstar, Rc, pI, Ienv, voff):
-    """Unconvolved model on the cropped layer-0 grid (:454-473)."""
+          Mstar, Rc, pI, Ienv, voff, kchunk=None):
+    """Unconvolved model on the cropped layer-0 grid (:454-473).
+
+    `kchunk` (channels per pass) only bounds the memory of the whole-array
+    temporaries at the largest cubes: every operation below is elementwise
+    along the channel axis, so the result is bit-identical to one pass."""
+    nv = len(setup['v_valid'])
+    if kchunk is not None and kchunk < nv:
+        parts = [iunif(dict(setup, v_valid=setup['v_valid'][k0:k0 + kchunk]), xs_list,
+                       vlos_list, Ynest, prof, prof_n, prof_d, Mstar, Rc, pI, Ienv, voff)
+                 for k0 in range(0, nv, kchunk)]
+        return np.concatenate(parts, axis=0)
     total = 0
     for vl0, xs in zip(vlos_list, xs_list):
         if vl0 is None:
@@ -358,7 +368,7 @@ def scale_factor(setup, cube):
     return s, gf, ff
 
 
-def cubemodel(setup, p, convolving=True, stages=None):
+def cubemodel(setup, p, convolving=True, stages=None, kchunk=None):
     """`ChannelFit.cubemodel` with every parameter group recomputed (:499-537);
     `setup['scaling']` selects 'uniform' or one of the 'mom0*' variants (then
     stages 'Iregrid' = regridded unconvolved cube, 'Iconv' = the same after
@@ -383,7 +393,7 @@ def cubemodel(setup, p, convolving=True, stages=None):
             Iu = np.zeros((len(setup['v_valid']), nneed, nneed))
         else:
             Iu = iunif(setup, xs, vl, Ynest, prof, prof_n, prof_d,
-                       Mstar, Rc, pI, Ienv, voff)
+                       Mstar, Rc, pI, Ienv, voff, kchunk=kchunk)
         if 'mom0' in setup.get('scaling', 'uniform'):              # :520-532
             Io = regrid(setup, xoff, yoff, Iu)
             m0 = np.sum(Io, axis=0) * setup['dv']
@@ -408,8 +418,8 @@ def chi2(setup, model):
             / setup['sigma']**2 / setup['pixperbeam'])
 
 
-def chi2_of(setup, p):
-    return chi2(setup, cubemodel(setup, p))
+def chi2_of(setup, p, kchunk=None):
+    return chi2(setup, cubemodel(setup, p, kchunk=kchunk))
 
 
 def lnprob_batch(setup, P):

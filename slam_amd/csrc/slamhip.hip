@@ -1483,7 +1483,11 @@ k_finalize(FitK g, const double* __restrict__ partial, int nblk,
     double s = a / b;
     if (b == 0.0 || s < 0.0) s = 0.0;
     double c2;
-    if (g.data_has_nan || a != a || b != b) {
+    if (b == 0.0) {
+      // ff == 0 is tested first (:489): scale 0 whatever gf is, the model is 0 and
+      // chi2 = nansum(data^2) (ssq_data skips NaNs like nansum, :601)
+      c2 = g.ssq_data / (g.sigma * g.sigma) / g.pixperbeam;
+    } else if (g.data_has_nan || a != a || b != b) {
       // np.sum propagates the NaN into the scale, the whole model becomes NaN
       // and nansum() of an all-NaN residual is 0 (:486-489, :601).
       c2 = 0.0;
@@ -1989,18 +1993,49 @@ __global__ void k_scale(double* __restrict__ cube, long long n,
 // ===========================================================================
 // Host side
 // ===========================================================================
+// Device scratch of one launch group: everything k_prep .. k_finalize write for
+// up to `wgroup` walkers.  A context owns one set, carved from a single device
+// allocation.
+struct Scratch {
+  int wgroup = 0;              // walkers per launch group
+  WalkerK* wk = nullptr;
+  double* params = nullptr;
+  double2* geom = nullptr;     // [walker][surface][sample] {vlos*sqrt(M), weight}
+  unsigned* gflag = nullptr;   // [walker][sample / 64] bit s: surface s of these 64 samples was stored
+  double* iunif = nullptr;
+  double* partial = nullptr;
+  double* stats = nullptr;
+  double* tk = nullptr;        // [walker][nvpad] scaled channel table (FitK::tk of a launch)
+  double* chi2 = nullptr;
+  int* cellx = nullptr;
+  int* celly = nullptr;
+  double* fracx = nullptr;
+  double* fracy = nullptr;
+  unsigned char* flags = nullptr;     // [walker][nv][fty][ftx] occupancy of Iunif tiles
+  unsigned char* winflag = nullptr;   // [walker][nv][wny][wnx] conv windows with emission
+  WinDesc* livelist = nullptr;
+  int* livecount = nullptr;
+  int* tile_ix = nullptr;
+  int* tile_jy = nullptr;
+  // Calls that use this set are ordered: `done` is recorded behind the last
+  // launch that touched it, and a call on another stream waits for it first.
+  hipEvent_t done = nullptr;
+  hipStream_t last = nullptr;
+  bool used = false;
+};
+
 struct slamhip_ctx {
   int device = 0;
   FitK k{};
   std::string err;
   std::vector<void*> allocs;
-  // per-group scratch
-  int wgroup = 0;          // walkers per launch group
-  WalkerK* d_wk = nullptr;
-  double* d_params = nullptr;
-  double2* d_geom = nullptr;   // [walker][surface][sample] {vlos*sqrt(M), weight}
-  unsigned* d_gflag = nullptr; // [walker][sample / 64] bit s: surface s of these 64 samples was stored
-  double* d_iunif = nullptr;
+  int wgroup = 0;          // walkers per launch group of `own`
+  Scratch own;             // per-group scratch, one allocation
+  size_t max_blocks = 0;   // partial-sum slots per walker
+  double* d_stage_p = nullptr;   // slamhip_chi2_batch: parameter / chi2 staging, grown on demand
+  double* d_stage_c = nullptr;
+  size_t stage_cap = 0;
+  double* d_cube = nullptr;      // slamhip_cubemodel: one observed-grid cube, allocated at its first call
   double* d_iconv = nullptr;   // dense convolved cubes: one walker at create, grown on demand (dense mode only)
   int iconv_walkers = 0;
   double* d_obs = nullptr;     // 'mom0*' scalings: [walker][nv][ny][nx] regridded cube
@@ -2017,21 +2052,8 @@ struct slamhip_ctx {
   unsigned char* d_obflag = nullptr;  // [walker][nv][tiles] emission under k_conv_obs_sep tiles
   double* d_obempty = nullptr;        // [nv][tiles] residual sum of an empty tile (= sum data^2)
   int ob_nty = 0;
-  double* d_partial = nullptr;
-  double* d_stats = nullptr;
-  double* d_chi2 = nullptr;
-  int* d_cellx = nullptr;
-  int* d_celly = nullptr;
-  double* d_fracx = nullptr;
-  double* d_fracy = nullptr;
-  unsigned char* d_flags = nullptr;   // [walker][nv][fty][ftx] occupancy of Iunif tiles
   int ftx = 1, fty = 1;
-  unsigned char* d_winflag = nullptr; // [walker][nv][wny][wnx] conv windows with emission (+ counter)
-  WinDesc* d_livelist = nullptr;
-  int* d_livecount = nullptr;
   int persist_blocks = 1;
-  int* d_tile_ix = nullptr;
-  int* d_tile_jy = nullptr;
   int fused = 0;           // hot path uses k_conv_chi2
   dim3 fz_grid{1, 1, 1};   // k_conv_chi2 grid for ONE walker (z = nv)
   int fz_sx = 1, fz_sy = 1;
@@ -2109,6 +2131,60 @@ int dev_upload(slamhip_ctx* c, const T** p, const T* host, size_t count) {
   if (rc) return rc;
   HIP_TRY(c, hipMemcpy(q, host, count * sizeof(T), hipMemcpyHostToDevice));
   *p = q;
+  return SLAMHIP_OK;
+}
+
+// Lays a scratch set for W walkers out behind `base` in 256-byte aligned pieces
+// and returns the bytes it takes.  base == nullptr: size only; s may be null.
+size_t carve(const slamhip_ctx* c, size_t W, unsigned char* base, Scratch* s) {
+  const FitK& k = c->k;
+  const size_t n = k.nneed;
+  const size_t nwin = W * k.nv * c->fz_grid.x * c->fz_grid.y;
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    unsigned char* p = base ? base + off : nullptr;
+    off += (std::max<size_t>(bytes, 1) + 255) / 256 * 256;
+    return p;
+  };
+  Scratch t;
+  t.wk = reinterpret_cast<WalkerK*>(take(W * sizeof(WalkerK)));
+  t.params = reinterpret_cast<double*>(take(W * NP * sizeof(double)));
+  t.geom = reinterpret_cast<double2*>(take(W * 4 * (size_t)k.nslot * sizeof(double2)));
+  t.gflag = reinterpret_cast<unsigned*>(take(W * (size_t)(k.nslot / 64) * sizeof(unsigned)));
+  t.iunif = reinterpret_cast<double*>(take(W * k.nv * n * n * sizeof(double)));
+  t.partial = reinterpret_cast<double*>(take(W * c->max_blocks * 3 * sizeof(double)));
+  t.stats = reinterpret_cast<double*>(take(W * 6 * sizeof(double)));
+  t.tk = reinterpret_cast<double*>(take(W * (size_t)k.nvpad * sizeof(double)));
+  t.chi2 = reinterpret_cast<double*>(take(W * sizeof(double)));
+  t.cellx = reinterpret_cast<int*>(take(W * k.nx * sizeof(int)));
+  t.fracx = reinterpret_cast<double*>(take(W * k.nx * sizeof(double)));
+  t.celly = reinterpret_cast<int*>(take(W * k.ny * sizeof(int)));
+  t.fracy = reinterpret_cast<double*>(take(W * k.ny * sizeof(double)));
+  t.flags = take(W * k.nv * c->ftx * c->fty + 8);   // +8: k_compact reads rows 8 bytes at a time
+  t.winflag = take(nwin);
+  t.livelist = reinterpret_cast<WinDesc*>(take(nwin * sizeof(WinDesc)));
+  t.livecount = reinterpret_cast<int*>(take(64 * sizeof(int)));
+  t.tile_ix = reinterpret_cast<int*>(take(W * c->fz_grid.x * 2 * sizeof(int)));
+  t.tile_jy = reinterpret_cast<int*>(take(W * c->fz_grid.y * 2 * sizeof(int)));
+  if (s && base) {
+    t.wgroup = s->wgroup; t.done = s->done; t.last = s->last; t.used = s->used;
+    *s = t;
+  }
+  return off;
+}
+
+// Calls that share a scratch set are ordered on the device: a call on another
+// stream than the set's last user first waits for that user's last launch.
+int scratch_acquire(slamhip_ctx* c, Scratch& S, hipStream_t st) {
+  if (S.done && S.used && S.last != st) HIP_TRY(c, hipStreamWaitEvent(st, S.done, 0));
+  return SLAMHIP_OK;
+}
+int scratch_release(slamhip_ctx* c, Scratch& S, hipStream_t st) {
+  if (S.done) {
+    HIP_TRY(c, hipEventRecord(S.done, st));
+    S.last = st;
+    S.used = true;
+  }
   return SLAMHIP_OK;
 }
 
@@ -2263,33 +2339,34 @@ int ensure_iconv(slamhip_ctx* c, int nw) {
 // Stages shared by every entry point: params (device) -> iunif for `nw` walkers
 // `dense`: the consumer reads Iunif without the occupancy flags, so tiles that
 // k_profile skips must already hold zeros.
-int run_model(slamhip_ctx* c, const double* d_params, int nw, hipStream_t st, bool dense) {
-  const FitK& k = c->k;
+int run_model(slamhip_ctx* c, Scratch& S, const double* d_params, int nw, hipStream_t st, bool dense) {
+  FitK k = c->k;
+  k.tk = S.tk;
   if (dense)
-    HIP_TRY(c, hipMemsetAsync(c->d_iunif, 0, sizeof(double) * (size_t)nw * k.nv * k.nneed * k.nneed, st));
+    HIP_TRY(c, hipMemsetAsync(S.iunif, 0, sizeof(double) * (size_t)nw * k.nv * k.nneed * k.nneed, st));
   {
     Timed t_(c, KID_PREP, st);
-    hipLaunchKernelGGL(k_prep, dim3(nw), dim3(256), 0, st, k, d_params, nw, c->d_wk,
-                       c->d_cellx, c->d_fracx, c->d_celly, c->d_fracy, c->d_tile_ix,
-                       c->d_tile_jy, (int)c->fz_grid.x, (int)c->fz_grid.y, c->fz_sx, c->fz_sy,
-                       c->d_winflag, (int)(k.nv * c->fz_grid.x * c->fz_grid.y), c->d_livecount);
+    hipLaunchKernelGGL(k_prep, dim3(nw), dim3(256), 0, st, k, d_params, nw, S.wk,
+                       S.cellx, S.fracx, S.celly, S.fracy, S.tile_ix,
+                       S.tile_jy, (int)c->fz_grid.x, (int)c->fz_grid.y, c->fz_sx, c->fz_sy,
+                       S.winflag, (int)(k.nv * c->fz_grid.x * c->fz_grid.y), S.livecount);
   }
   {
     Timed t_(c, KID_SURFACE, st);
     dim3 g1((unsigned)((k.nslot + 255) / 256), 1, (nw + SURF_WPT - 1) / SURF_WPT);
-    hipLaunchKernelGGL(k_surface, g1, dim3(256), 0, st, k, c->d_wk, c->d_geom, c->d_gflag, nw);
+    hipLaunchKernelGGL(k_surface, g1, dim3(256), 0, st, k, S.wk, S.geom, S.gflag, nw);
   }
   {
     Timed t_(c, KID_PROFILE, st);
     const int tgroups = (c->ftx * c->fty + 7) / 8;
     dim3 g2((unsigned)tgroups * 8u * (unsigned)(k.nvpad / CH) * (unsigned)nw, 1, 1);
     if (k.fast_idx)
-      hipLaunchKernelGGL(k_profile<true>, g2, dim3(256), 0, st, k, c->d_wk, c->d_geom, c->d_gflag,
-                         c->d_iunif, c->d_flags, c->ftx, c->fty, c->d_winflag, (int)c->fz_grid.x, (int)c->fz_grid.y,
+      hipLaunchKernelGGL(k_profile<true>, g2, dim3(256), 0, st, k, S.wk, S.geom, S.gflag,
+                         S.iunif, S.flags, c->ftx, c->fty, S.winflag, (int)c->fz_grid.x, (int)c->fz_grid.y,
                          c->fz_sx, c->fz_sy);
     else
-      hipLaunchKernelGGL(k_profile<false>, g2, dim3(256), 0, st, k, c->d_wk, c->d_geom, c->d_gflag,
-                         c->d_iunif, c->d_flags, c->ftx, c->fty, c->d_winflag, (int)c->fz_grid.x, (int)c->fz_grid.y,
+      hipLaunchKernelGGL(k_profile<false>, g2, dim3(256), 0, st, k, S.wk, S.geom, S.gflag,
+                         S.iunif, S.flags, c->ftx, c->fty, S.winflag, (int)c->fz_grid.x, (int)c->fz_grid.y,
                          c->fz_sx, c->fz_sy);
   }
   HIP_TRY(c, hipGetLastError());
@@ -2299,10 +2376,10 @@ int run_model(slamhip_ctx* c, const double* d_params, int nw, hipStream_t st, bo
 // 'mom0*' scalings: Iunif -> observed grid -> per-pixel moment-0 scale -> beam on
 // the observed grid -> residual sum.  `d_model` (may be null) receives the
 // model cubes [nw][nv][ny][nx].
-int run_group_mom0(slamhip_ctx* c, const double* d_params, int nw, double* d_chi2,
+int run_group_mom0(slamhip_ctx* c, Scratch& S, const double* d_params, int nw, double* d_chi2,
                    double* d_model, bool convolving, hipStream_t st) {
   const FitK& k = c->k;
-  int rc = run_model(c, d_params, nw, st, false);
+  int rc = run_model(c, S, d_params, nw, st, false);
   if (rc) return rc;
   {
     Timed t_(c, KID_REGRID, st);
@@ -2311,13 +2388,13 @@ int run_group_mom0(slamhip_ctx* c, const double* d_params, int nw, double* d_chi
     if (flagged)
       HIP_TRY(c, hipMemsetAsync(c->d_obflag, 0, (size_t)nw * k.nv * c->ob_grid.x * c->ob_nty, st));
     const int ntile = c->ftx * c->fty;
-    hipLaunchKernelGGL(k_tile_krange, dim3((ntile + 255) / 256, nw), dim3(256), 0, st, k, c->d_flags,
+    hipLaunchKernelGGL(k_tile_krange, dim3((ntile + 255) / 256, nw), dim3(256), 0, st, k, S.flags,
                        ntile, c->d_krange);
     const int nseg = (k.nx + 63) / 64;
     if (flagged)
       HIP_TRY(c, hipMemsetAsync(c->d_rowflag, 0, (size_t)nw * k.nv * k.ny * nseg, st));
     hipLaunchKernelGGL(k_regrid_mom0, dim3(nseg, (k.ny + 3) / 4, nw), dim3(256), 0, st, k,
-                       c->d_cellx, c->d_fracx, c->d_celly, c->d_fracy, c->d_iunif, c->d_flags,
+                       S.cellx, S.fracx, S.celly, S.fracy, S.iunif, S.flags,
                        c->d_krange, c->ftx, c->fty, c->d_obs, flagged ? c->d_obflag : (unsigned char*)nullptr,
                        c->ob_ty ? c->ob_ty : 1, (int)c->ob_grid.x, c->ob_nty,
                        flagged ? c->d_rowflag : (unsigned char*)nullptr);
@@ -2336,11 +2413,11 @@ int run_group_mom0(slamhip_ctx* c, const double* d_params, int nw, double* d_chi
       const long long nwin = (long long)g.x * g.y * g.z;
       HIP_TRY(c, hipMemsetAsync(c->d_obcount, 0, 2 * sizeof(int), st));
       hipLaunchKernelGGL(k_obs_list, dim3((unsigned)((nwin + 255) / 256)), dim3(256), 0, st, k,
-                         c->d_obflag, c->d_obempty, c->d_partial, c->d_oblist, c->d_obcount,
+                         c->d_obflag, c->d_obempty, S.partial, c->d_oblist, c->d_obcount,
                          (int)g.x, (int)g.y, c->ob_ty, nwin);
 #define SLAM_OBL(TY_, NIT_)                                                                   \
       hipLaunchKernelGGL((k_conv_obs_live<TY_, NIT_>), dim3(c->ob_persist), dim3(256), c->ob_lds, st, k, \
-                         c->d_obs, c->d_partial, c->kpad, c->nrank, k.gx_pad, k.gy_pad, c->d_rowflag, \
+                         c->d_obs, S.partial, c->kpad, c->nrank, k.gx_pad, k.gy_pad, c->d_rowflag, \
                          c->d_oblist, c->d_obcount, (int)g.x, (int)g.y)
       if (c->ob_ty == 32 && c->ob_nit == 2) SLAM_OBL(32, 2);
       else if (c->ob_ty == 32) SLAM_OBL(32, 4);
@@ -2349,7 +2426,7 @@ int run_group_mom0(slamhip_ctx* c, const double* d_params, int nw, double* d_chi
     } else {
 #define SLAM_OBS(TY_, NIT_, WR_)                                                            \
     hipLaunchKernelGGL((k_conv_obs_sep<TY_, NIT_, WR_>), g, dim3(256), c->ob_lds, st, k, c->d_obs, \
-                       d_model, c->d_partial, c->kpad, c->nrank, c->d_obflag, c->d_obempty, k.gx_pad, k.gy_pad, \
+                       d_model, S.partial, c->kpad, c->nrank, c->d_obflag, c->d_obempty, k.gx_pad, k.gy_pad, \
                        c->d_rowflag)
     if (c->ob_ty == 32 && c->ob_nit == 2) { if (d_model) SLAM_OBS(32, 2, true); else SLAM_OBS(32, 2, false); }
     else if (c->ob_ty == 32)              { if (d_model) SLAM_OBS(32, 4, true); else SLAM_OBS(32, 4, false); }
@@ -2358,8 +2435,8 @@ int run_group_mom0(slamhip_ctx* c, const double* d_params, int nw, double* d_chi
     }
     const int nblk = (int)(g.x * g.y) * k.nv;
     Timed t2_(c, KID_FINALIZE, st);
-    hipLaunchKernelGGL(k_sum_chi2, dim3(nw), dim3(256), 0, st, k, c->d_partial, nblk,
-                       c->d_stats, d_chi2);
+    hipLaunchKernelGGL(k_sum_chi2, dim3(nw), dim3(256), 0, st, k, S.partial, nblk,
+                       S.stats, d_chi2);
     HIP_TRY(c, hipGetLastError());
     return SLAMHIP_OK;
   }
@@ -2370,36 +2447,36 @@ int run_group_mom0(slamhip_ctx* c, const double* d_params, int nw, double* d_chi
     dim3 g(c->ob_grid.x, c->ob_grid.y, c->ob_grid.z * nw);
     if (d_model)
       hipLaunchKernelGGL((k_conv_obs<true>), g, dim3(256), c->c2d_lds, st, k, c->d_obs, d_model,
-                         c->d_partial);
+                         S.partial);
     else
       hipLaunchKernelGGL((k_conv_obs<false>), g, dim3(256), c->c2d_lds, st, k, c->d_obs,
-                         (double*)nullptr, c->d_partial);
+                         (double*)nullptr, S.partial);
   }
   {
     Timed t_(c, KID_FINALIZE, st);
-    hipLaunchKernelGGL(k_sum_chi2, dim3(nw), dim3(256), 0, st, k, c->d_partial, c->ob_blocks,
-                       c->d_stats, d_chi2);
+    hipLaunchKernelGGL(k_sum_chi2, dim3(nw), dim3(256), 0, st, k, S.partial, c->ob_blocks,
+                       S.stats, d_chi2);
   }
   HIP_TRY(c, hipGetLastError());
   return SLAMHIP_OK;
 }
 
-int run_group(slamhip_ctx* c, const double* d_params, int nw, double* d_chi2,
+int run_group(slamhip_ctx* c, Scratch& S, const double* d_params, int nw, double* d_chi2,
               hipStream_t st) {
-  if (c->k.mom0decon) return run_group_mom0(c, d_params, nw, d_chi2, nullptr, true, st);
+  if (c->k.mom0decon) return run_group_mom0(c, S, d_params, nw, d_chi2, nullptr, true, st);
   const bool fused = c->fused && c->conv_mode != 1;
   // conv mode 2 keeps the factorised beam where mode 0 would take direct taps
   const int fz_rank = (c->conv_mode == 2 && c->nrank >= 1) ? c->nrank : c->fz_rank;
-  int rc = run_model(c, d_params, nw, st, !fused);
+  int rc = run_model(c, S, d_params, nw, st, !fused);
   if (rc) return rc;
   if (fused) {
     const int nwin = (int)(c->fz_grid.x * c->fz_grid.y * c->fz_grid.z) * nw;
     {
       Timed t_(c, KID_COMPACT, st);
-      hipLaunchKernelGGL(k_compact, dim3((nwin + 255) / 256), dim3(256), 0, st, c->k, c->d_winflag, nwin,
-                         c->d_flags, c->ftx, c->fty, c->d_tile_ix, c->d_tile_jy,
+      hipLaunchKernelGGL(k_compact, dim3((nwin + 255) / 256), dim3(256), 0, st, c->k, S.winflag, nwin,
+                         S.flags, c->ftx, c->fty, S.tile_ix, S.tile_jy,
                          (int)c->fz_grid.x, (int)c->fz_grid.y, c->fz_sx, c->fz_sy, c->fz_sy + 1,
-                         c->d_livelist, c->d_livecount);
+                         S.livelist, S.livecount);
     }
     {
       Timed t_(c, KID_CONV, st);
@@ -2407,17 +2484,17 @@ int run_group(slamhip_ctx* c, const double* d_params, int nw, double* d_chi2,
       const size_t fz_lds = fz_rank ? c->fz_lds : c->fz_lds_direct;
 #define SLAM_FUSED(TY_, MR_, DIR_)                                                        \
       hipLaunchKernelGGL((k_conv_chi2<TY_, MR_, DIR_>), gz, dim3(CV_NT), fz_lds, st, c->k, \
-                         c->d_iunif, c->d_cellx, c->d_fracx, c->d_celly, c->d_fracy,       \
-                         c->d_livelist, c->d_livecount, (int)c->fz_grid.x, (int)c->fz_grid.y, \
-                         c->d_partial, c->kpad, fz_rank, c->k.gx_pad, c->k.gy_pad, c->k.beam_ft)
+                         S.iunif, S.cellx, S.fracx, S.celly, S.fracy,       \
+                         S.livelist, S.livecount, (int)c->fz_grid.x, (int)c->fz_grid.y, \
+                         S.partial, c->kpad, fz_rank, c->k.gx_pad, c->k.gy_pad, c->k.beam_ft)
       switch (c->sep_variant) {
         case 0:
           if (fz_rank) SLAM_FUSED(64, 2, false);
           else if (c->direct_fixed)
             hipLaunchKernelGGL((k_conv_chi2<64, 2, true, DIRECT_PITCH>), gz, dim3(CV_NT), fz_lds, st, c->k,
-                               c->d_iunif, c->d_cellx, c->d_fracx, c->d_celly, c->d_fracy,
-                               c->d_livelist, c->d_livecount, (int)c->fz_grid.x, (int)c->fz_grid.y,
-                               c->d_partial, c->kpad, fz_rank, c->k.gx_pad, c->k.gy_pad, c->k.beam_ft);
+                               S.iunif, S.cellx, S.fracx, S.celly, S.fracy,
+                               S.livelist, S.livecount, (int)c->fz_grid.x, (int)c->fz_grid.y,
+                               S.partial, c->kpad, fz_rank, c->k.gx_pad, c->k.gy_pad, c->k.beam_ft);
           else SLAM_FUSED(64, 2, true);
           break;
         case 1: if (fz_rank) SLAM_FUSED(64, 3, false); else SLAM_FUSED(64, 3, true); break;
@@ -2427,27 +2504,28 @@ int run_group(slamhip_ctx* c, const double* d_params, int nw, double* d_chi2,
     }
     {
       Timed t_(c, KID_FINALIZE, st);
-      hipLaunchKernelGGL(k_finalize, dim3(nw), dim3(256), 0, st, c->k, c->d_partial,
-                         (int)(c->fz_grid.x * c->fz_grid.y * c->fz_grid.z), c->d_winflag,
-                         c->d_stats, d_chi2);
+      hipLaunchKernelGGL(k_finalize, dim3(nw), dim3(256), 0, st, c->k, S.partial,
+                         (int)(c->fz_grid.x * c->fz_grid.y * c->fz_grid.z), S.winflag,
+                         S.stats, d_chi2);
     }
     HIP_TRY(c, hipGetLastError());
     return SLAMHIP_OK;
   }
-  if ((rc = ensure_iconv(c, nw))) return rc;
-  rc = run_conv(c, c->d_iunif, c->d_iconv, nw * c->k.nv, st);
+  if (nw > c->iconv_walkers)                  // group_cap() keeps dense groups within the buffer
+    return fail(c, SLAMHIP_ERR_STATE, "dense conv buffer holds %d walkers, group has %d", c->iconv_walkers, nw);
+  rc = run_conv(c, S.iunif, c->d_iconv, nw * c->k.nv, st);
   if (rc) return rc;
   {
     Timed t_(c, KID_REGRID, st);
     dim3 g4(c->rg_grid.x, c->rg_grid.y, c->rg_grid.z * nw);
-    hipLaunchKernelGGL((k_regrid<false>), g4, dim3(RED_THREADS), 0, st, c->k, c->d_cellx,
-                       c->d_fracx, c->d_celly, c->d_fracy, c->d_iconv, c->d_partial,
+    hipLaunchKernelGGL((k_regrid<false>), g4, dim3(RED_THREADS), 0, st, c->k, S.cellx,
+                       S.fracx, S.celly, S.fracy, c->d_iconv, S.partial,
                        (double*)nullptr);
   }
   {
     Timed t_(c, KID_FINALIZE, st);
-    hipLaunchKernelGGL(k_finalize, dim3(nw), dim3(256), 0, st, c->k, c->d_partial,
-                       c->red_blocks, (const unsigned char*)nullptr, c->d_stats, d_chi2);
+    hipLaunchKernelGGL(k_finalize, dim3(nw), dim3(256), 0, st, c->k, S.partial,
+                       c->red_blocks, (const unsigned char*)nullptr, S.stats, d_chi2);
   }
   HIP_TRY(c, hipGetLastError());
   return SLAMHIP_OK;
@@ -2688,15 +2766,6 @@ int slamhip_create(const slamhip_desc* d, slamhip_ctx** out) {
   if ((rc = dev_upload(c, &k.tile_nl, tile_nl.data(), tile_nl.size()))) return rc;
 
   // --- per-group scratch -----------------------------------------------------
-  const size_t per_walker = sizeof(double) * (8 * (size_t)k.nslot + (size_t)k.nv * n * n +
-                                              (d->mom0decon ? ncube : 0));
-  size_t freeb = 0, totalb = 0;
-  HIP_TRY(c, hipMemGetInfo(&freeb, &totalb));
-  size_t budget = d->max_scratch_bytes > 0 ? (size_t)d->max_scratch_bytes : ((size_t)64 << 30);
-  budget = std::min(budget, freeb / 10 * 7);
-  c->wgroup = (int)std::max<size_t>(1, std::min<size_t>(128, budget / per_walker));
-  // keep conv's grid.z within limits
-  while (c->wgroup > 1 && (long long)c->wgroup * k.nv > 32768) --c->wgroup;
   c->rg_grid = dim3((k.nx + RED_THREADS - 1) / RED_THREADS, (k.ny + RG_ROWS - 1) / RG_ROWS, k.nv);
   c->red_blocks = (int)(c->rg_grid.x * c->rg_grid.y * c->rg_grid.z);
   if (d->mom0decon && c->nrank >= 1) {
@@ -2727,29 +2796,37 @@ int slamhip_create(const slamhip_desc* d, slamhip_ctx** out) {
   }
   c->ob_grid = dim3((k.nx + C2_TX - 1) / C2_TX, (k.ny + C2_TY - 1) / C2_TY, k.nv);
   c->ob_blocks = (int)(c->ob_grid.x * c->ob_grid.y * c->ob_grid.z);
-  const size_t max_blocks = std::max<size_t>(std::max<size_t>(c->red_blocks, c->ob_blocks),
-                                             (size_t)c->fz_grid.x * c->fz_grid.y * c->fz_grid.z);
-  const size_t W = c->wgroup;
-  if ((rc = dev_alloc(c, &c->d_wk, W))) return rc;
-  if ((rc = dev_alloc(c, &c->d_params, W * NP))) return rc;
-  if ((rc = dev_alloc(c, &c->d_geom, W * 4 * k.nslot))) return rc;
-  if ((rc = dev_alloc(c, &c->d_gflag, W * (size_t)(k.nslot / 64)))) return rc;
-  if ((rc = dev_alloc(c, &c->d_iunif, W * k.nv * n * n))) return rc;
-  if ((rc = ensure_iconv(c, 1))) return rc;
-  if (d->mom0decon && (rc = dev_alloc(c, &c->d_obs, W * ncube))) return rc;
-  if ((rc = dev_alloc(c, &c->d_partial, W * max_blocks * 3))) return rc;
-  if ((rc = dev_alloc(c, &c->d_stats, W * 6))) return rc;
-  if ((rc = dev_alloc(c, &k.tk, W * (size_t)k.nvpad))) return rc;
-  if ((rc = dev_alloc(c, &c->d_chi2, W))) return rc;
-  if ((rc = dev_alloc(c, &c->d_cellx, W * k.nx))) return rc;
-  if ((rc = dev_alloc(c, &c->d_fracx, W * k.nx))) return rc;
-  if ((rc = dev_alloc(c, &c->d_celly, W * k.ny))) return rc;
-  if ((rc = dev_alloc(c, &c->d_fracy, W * k.ny))) return rc;
+  c->max_blocks = std::max<size_t>(std::max<size_t>(c->red_blocks, c->ob_blocks),
+                                   (size_t)c->fz_grid.x * c->fz_grid.y * c->fz_grid.z);
   c->ftx = (n + PT_X - 1) / PT_X;
   c->fty = (n + PT_Y - 1) / PT_Y;
-  if ((rc = dev_alloc(c, &c->d_flags, W * k.nv * c->ftx * c->fty + 8))) return rc;   // +8: k_compact reads rows 8 bytes at a time
+  const size_t nseg = (size_t)(k.nx + 63) / 64;
+  // what one more walker costs: its share of the scratch set plus, for the 'mom0*'
+  // scalings, its regridded cube and row-segment marks
+  const size_t mom0_walker = d->mom0decon ? ncube * sizeof(double) + (size_t)k.nv * k.ny * nseg : 0;
+  const size_t per_walker = carve(c, 1, nullptr, nullptr) + mom0_walker;
+  size_t freeb = 0, totalb = 0;
+  HIP_TRY(c, hipMemGetInfo(&freeb, &totalb));
+  size_t budget = d->max_scratch_bytes > 0 ? (size_t)d->max_scratch_bytes : ((size_t)64 << 30);
+  budget = std::min(budget, freeb / 10 * 7);
+  c->wgroup = (int)std::max<size_t>(1, std::min<size_t>(128, budget / per_walker));
+  // keep conv's grid.z within limits
+  while (c->wgroup > 1 && (long long)c->wgroup * k.nv > 32768) --c->wgroup;
+  while (c->wgroup > 1 && carve(c, c->wgroup, nullptr, nullptr) + c->wgroup * mom0_walker > budget) --c->wgroup;
+  const size_t W = c->wgroup;
+  Scratch& S = c->own;
+  {
+    unsigned char* base = nullptr;
+    if ((rc = dev_alloc(c, &base, carve(c, W, nullptr, nullptr)))) return rc;
+    carve(c, W, base, &S);
+    S.wgroup = c->wgroup;
+    k.tk = S.tk;
+    HIP_TRY(c, hipEventCreateWithFlags(&S.done, hipEventDisableTiming));
+  }
+  if ((rc = ensure_iconv(c, 1))) return rc;
+  if (d->mom0decon && (rc = dev_alloc(c, &c->d_obs, W * ncube))) return rc;
   if (d->mom0decon && (rc = dev_alloc(c, &c->d_krange, W * (size_t)c->ftx * c->fty))) return rc;
-  if (d->mom0decon && (rc = dev_alloc(c, &c->d_rowflag, W * (size_t)k.nv * k.ny * ((k.nx + 63) / 64)))) return rc;
+  if (d->mom0decon && (rc = dev_alloc(c, &c->d_rowflag, W * (size_t)k.nv * k.ny * nseg))) return rc;
   {
     // a conv window must not span more occupancy bytes than its LDS table holds
     const int ty = c->sep_variant == 2 ? 32 : 64;
@@ -2758,10 +2835,6 @@ int slamhip_create(const slamhip_desc* d, slamhip_ctx** out) {
     if ((int)(c->fz_grid.x + c->fz_grid.y) > PREP_TILES) c->fused = 0;
   }
   {
-    const size_t nwin = W * k.nv * c->fz_grid.x * c->fz_grid.y;
-    if ((rc = dev_alloc(c, &c->d_winflag, nwin))) return rc;
-    if ((rc = dev_alloc(c, &c->d_livelist, nwin))) return rc;
-    if ((rc = dev_alloc(c, &c->d_livecount, 64))) return rc;
     hipDeviceProp_t prop;
     HIP_TRY(c, hipGetDeviceProperties(&prop, c->device));
     const int per_cu = std::max(1, (int)((160 * 1024) / std::max<size_t>(c->fz_lds + 2048, 1)));
@@ -2769,8 +2842,6 @@ int slamhip_create(const slamhip_desc* d, slamhip_ctx** out) {
     const int per_cu_d = std::max(1, (int)((160 * 1024) / std::max<size_t>(c->fz_lds_direct + 2048, 1)));
     c->persist_direct = prop.multiProcessorCount * std::min(per_cu_d, 8);
   }
-  if ((rc = dev_alloc(c, &c->d_tile_ix, W * c->fz_grid.x * 2))) return rc;
-  if ((rc = dev_alloc(c, &c->d_tile_jy, W * c->fz_grid.y * 2))) return rc;
   HIP_TRY(c, hipStreamCreate(&c->stream));
   if (d->mom0decon && c->ob_ty) {
     // residual sum of every (channel, tile) when the model is zero there: this
@@ -2809,6 +2880,10 @@ void slamhip_destroy(slamhip_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)hipDeviceSynchronize();
   for (void* p : c->allocs) (void)hipFree(p);
+  if (c->d_stage_p) (void)hipFree(c->d_stage_p);
+  if (c->d_stage_c) (void)hipFree(c->d_stage_c);
+  if (c->own.done) (void)hipEventDestroy(c->own.done);
+  for (auto& sp : c->spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -2860,8 +2935,35 @@ int slamhip_beam_rank(slamhip_ctx* c) {
 
 int slamhip_set_conv_mode(slamhip_ctx* c, int mode) {
   if (!c || mode < 0 || mode > 2) return SLAMHIP_ERR_ARG;
+  if (mode == 1 && !c->k.mom0decon) {
+    // the dense path keeps whole convolved cubes: room for a few walkers per
+    // launch group is made here, so that the batch entry points never allocate
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = ensure_iconv(c, std::min(c->wgroup, 8));
+    if (rc) return rc;
+  }
   c->conv_mode = mode;
   return SLAMHIP_OK;
+}
+
+// Walkers one launch group may hold: the set's capacity, and in the dense
+// (non-fused) conv mode no more than there are convolved cubes for (the dense
+// buffer is grown by slamhip_set_conv_mode, never on the data path).
+static int group_cap(const slamhip_ctx* c, const Scratch& S) {
+  const bool fused = c->k.mom0decon || (c->fused && c->conv_mode != 1);
+  return fused ? S.wgroup : std::max(1, std::min(S.wgroup, c->iconv_walkers));
+}
+
+static int batch_on(slamhip_ctx* c, Scratch& S, const double* params_dev, int nw,
+                    double* chi2_dev, hipStream_t st) {
+  int rc = scratch_acquire(c, S, st);
+  if (rc) return rc;
+  const int cap = group_cap(c, S);
+  for (int w0 = 0; w0 < nw; w0 += cap) {
+    const int m = std::min(cap, nw - w0);
+    if ((rc = run_group(c, S, params_dev + (size_t)w0 * NP, m, chi2_dev + w0, st))) return rc;
+  }
+  return scratch_release(c, S, st);
 }
 
 int slamhip_chi2_batch_dev(slamhip_ctx* c, const double* params_dev, int nw,
@@ -2869,14 +2971,9 @@ int slamhip_chi2_batch_dev(slamhip_ctx* c, const double* params_dev, int nw,
   if (!c || c->wgroup < 1) return SLAMHIP_ERR_STATE;
   if (nw < 0 || (nw > 0 && (!params_dev || !chi2_dev)))
     return fail(c, SLAMHIP_ERR_ARG, "chi2_batch_dev: bad arguments");
+  if (nw == 0) return SLAMHIP_OK;
   HIP_TRY(c, hipSetDevice(c->device));
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  for (int w0 = 0; w0 < nw; w0 += c->wgroup) {
-    const int m = std::min(c->wgroup, nw - w0);
-    int rc = run_group(c, params_dev + (size_t)w0 * NP, m, chi2_dev + w0, st);
-    if (rc) return rc;
-  }
-  return SLAMHIP_OK;
+  return batch_on(c, c->own, params_dev, nw, chi2_dev, static_cast<hipStream_t>(stream));
 }
 
 int slamhip_chi2_batch(slamhip_ctx* c, const double* params, int nw, double* chi2_out) {
@@ -2885,20 +2982,25 @@ int slamhip_chi2_batch(slamhip_ctx* c, const double* params, int nw, double* chi
     return fail(c, SLAMHIP_ERR_ARG, "chi2_batch: bad arguments");
   if (nw == 0) return SLAMHIP_OK;
   HIP_TRY(c, hipSetDevice(c->device));
-  double *dp = nullptr, *dc = nullptr;
-  HIP_TRY(c, hipMalloc((void**)&dp, (size_t)nw * NP * sizeof(double)));
-  hipError_t e = hipMalloc((void**)&dc, (size_t)nw * sizeof(double));
-  if (e != hipSuccess) { (void)hipFree(dp); return fail(c, SLAMHIP_ERR_NOMEM, "hipMalloc chi2"); }
-  int rc = SLAMHIP_OK;
-  e = hipMemcpyAsync(dp, params, (size_t)nw * NP * sizeof(double), hipMemcpyHostToDevice, c->stream);
-  if (e == hipSuccess) rc = slamhip_chi2_batch_dev(c, dp, nw, dc, c->stream);
-  if (e == hipSuccess && rc == SLAMHIP_OK)
-    e = hipMemcpyAsync(chi2_out, dc, (size_t)nw * sizeof(double), hipMemcpyDeviceToHost, c->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-  (void)hipFree(dp);
-  (void)hipFree(dc);
+  if ((size_t)nw > c->stage_cap) {
+    // staging grows to the largest batch seen (a sampler sends the same size every step)
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->d_stage_p) (void)hipFree(c->d_stage_p);
+    if (c->d_stage_c) (void)hipFree(c->d_stage_c);
+    c->d_stage_p = c->d_stage_c = nullptr;
+    c->stage_cap = 0;
+    const size_t cap = std::max<size_t>((size_t)nw, 256);
+    HIP_TRY(c, hipMalloc((void**)&c->d_stage_p, cap * NP * sizeof(double)));
+    HIP_TRY(c, hipMalloc((void**)&c->d_stage_c, cap * sizeof(double)));
+    c->stage_cap = cap;
+  }
+  HIP_TRY(c, hipMemcpyAsync(c->d_stage_p, params, (size_t)nw * NP * sizeof(double),
+                            hipMemcpyHostToDevice, c->stream));
+  int rc = slamhip_chi2_batch_dev(c, c->d_stage_p, nw, c->d_stage_c, c->stream);
   if (rc) return rc;
-  if (e != hipSuccess) return fail(c, SLAMHIP_ERR_HIP, "chi2_batch: %s", hipGetErrorString(e));
+  HIP_TRY(c, hipMemcpyAsync(chi2_out, c->d_stage_c, (size_t)nw * sizeof(double),
+                            hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
   return SLAMHIP_OK;
 }
 
@@ -2907,46 +3009,59 @@ int slamhip_chi2_stats(slamhip_ctx* c, const double* params, int nw, double* sta
   if (nw < 0 || (nw > 0 && (!params || !stats_out)))
     return fail(c, SLAMHIP_ERR_ARG, "chi2_stats: bad arguments");
   HIP_TRY(c, hipSetDevice(c->device));
-  for (int w0 = 0; w0 < nw; w0 += c->wgroup) {
-    const int m = std::min(c->wgroup, nw - w0);
-    HIP_TRY(c, hipMemcpyAsync(c->d_params, params + (size_t)w0 * NP, (size_t)m * NP * sizeof(double),
+  Scratch& S = c->own;
+  int rc = scratch_acquire(c, S, c->stream);
+  if (rc) return rc;
+  const int cap = group_cap(c, S);
+  for (int w0 = 0; w0 < nw; w0 += cap) {
+    const int m = std::min(cap, nw - w0);
+    HIP_TRY(c, hipMemcpyAsync(S.params, params + (size_t)w0 * NP, (size_t)m * NP * sizeof(double),
                               hipMemcpyHostToDevice, c->stream));
-    int rc = run_group(c, c->d_params, m, c->d_chi2, c->stream);
-    if (rc) return rc;
-    HIP_TRY(c, hipMemcpyAsync(stats_out + (size_t)w0 * 6, c->d_stats, (size_t)m * 6 * sizeof(double),
+    if ((rc = run_group(c, S, S.params, m, S.chi2, c->stream))) return rc;
+    HIP_TRY(c, hipMemcpyAsync(stats_out + (size_t)w0 * 6, S.stats, (size_t)m * 6 * sizeof(double),
                               hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
   }
-  return SLAMHIP_OK;
+  return scratch_release(c, S, c->stream);
 }
 
+// Single-vector entry points: parameters into the context's scratch set on its
+// own stream, ordered behind whatever used the set last.
 static int single_prepare(slamhip_ctx* c, const double* params) {
   if (!c || c->wgroup < 1) return SLAMHIP_ERR_STATE;
   if (!params) return fail(c, SLAMHIP_ERR_ARG, "null params");
   HIP_TRY(c, hipSetDevice(c->device));
-  HIP_TRY(c, hipMemcpyAsync(c->d_params, params, NP * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  int rc = scratch_acquire(c, c->own, c->stream);
+  if (rc) return rc;
+  HIP_TRY(c, hipMemcpyAsync(c->own.params, params, NP * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  return SLAMHIP_OK;
+}
+
+// ... and their common end: wait for the stream, leave the set marked as used on it.
+static int single_finish(slamhip_ctx* c, hipError_t e, const char* what) {
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  (void)scratch_release(c, c->own, c->stream);
+  if (e != hipSuccess) return fail(c, SLAMHIP_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
   return SLAMHIP_OK;
 }
 
 int slamhip_iunif(slamhip_ctx* c, const double* params, double* out) {
   int rc = single_prepare(c, params);
   if (rc) return rc;
-  if ((rc = run_model(c, c->d_params, 1, c->stream, true))) return rc;
+  Scratch& S = c->own;
+  if ((rc = run_model(c, S, S.params, 1, c->stream, true))) return rc;
   const size_t nb = (size_t)c->k.nv * c->k.nneed * c->k.nneed * sizeof(double);
-  HIP_TRY(c, hipMemcpyAsync(out, c->d_iunif, nb, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
-  return SLAMHIP_OK;
+  return single_finish(c, hipMemcpyAsync(out, S.iunif, nb, hipMemcpyDeviceToHost, c->stream), "iunif");
 }
 
 int slamhip_iconv(slamhip_ctx* c, const double* params, double* out) {
   int rc = single_prepare(c, params);
   if (rc) return rc;
-  if ((rc = run_model(c, c->d_params, 1, c->stream, true))) return rc;
-  if ((rc = run_conv(c, c->d_iunif, c->d_iconv, c->k.nv, c->stream))) return rc;
+  Scratch& S = c->own;
+  if ((rc = run_model(c, S, S.params, 1, c->stream, true))) return rc;
+  if ((rc = run_conv(c, S.iunif, c->d_iconv, c->k.nv, c->stream))) return rc;
   const size_t nb = (size_t)c->k.nv * c->k.nneed * c->k.nneed * sizeof(double);
-  HIP_TRY(c, hipMemcpyAsync(out, c->d_iconv, nb, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
-  return SLAMHIP_OK;
+  return single_finish(c, hipMemcpyAsync(out, c->d_iconv, nb, hipMemcpyDeviceToHost, c->stream), "iconv");
 }
 
 int slamhip_cubemodel(slamhip_ctx* c, const double* params, int convolving,
@@ -2955,51 +3070,56 @@ int slamhip_cubemodel(slamhip_ctx* c, const double* params, int convolving,
   if (rc) return rc;
   if (!out) return fail(c, SLAMHIP_ERR_ARG, "null output");
   const FitK& k = c->k;
+  Scratch& S = c->own;
+  const size_t ncube = (size_t)k.nv * k.ny * k.nx;
+  if (!c->d_cube && (rc = dev_alloc(c, &c->d_cube, ncube))) return rc;   // kept for later calls
+  double* d_cube = c->d_cube;
   if (k.mom0decon) {
-    const size_t ncube = (size_t)k.nv * k.ny * k.nx;
-    double* d_cube = nullptr;
-    HIP_TRY(c, hipMalloc((void**)&d_cube, ncube * sizeof(double)));
-    rc = run_group_mom0(c, c->d_params, 1, c->d_chi2, d_cube, convolving != 0, c->stream);
-    hipError_t e = hipSuccess;
-    if (rc == SLAMHIP_OK)
-      e = hipMemcpyAsync(out, d_cube, ncube * sizeof(double), hipMemcpyDeviceToHost, c->stream);
-    if (rc == SLAMHIP_OK && e == hipSuccess && stats_out) {
+    rc = run_group_mom0(c, S, S.params, 1, S.chi2, d_cube, convolving != 0, c->stream);
+    if (rc) return rc;
+    hipError_t e = hipMemcpyAsync(out, d_cube, ncube * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess && stats_out) {
       if (convolving) {
-        e = hipMemcpyAsync(stats_out, c->d_stats, 4 * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+        e = hipMemcpyAsync(stats_out, S.stats, 4 * sizeof(double), hipMemcpyDeviceToHost, c->stream);
       } else {
         for (int i = 0; i < 4; ++i) stats_out[i] = std::numeric_limits<double>::quiet_NaN();
       }
     }
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    (void)hipFree(d_cube);
-    if (rc) return rc;
-    if (e != hipSuccess) return fail(c, SLAMHIP_ERR_HIP, "cubemodel: %s", hipGetErrorString(e));
-    return SLAMHIP_OK;
+    return single_finish(c, e, "cubemodel");
   }
-  if ((rc = run_model(c, c->d_params, 1, c->stream, true))) return rc;
+  if ((rc = run_model(c, S, S.params, 1, c->stream, true))) return rc;
   if (convolving) {
-    if ((rc = run_conv(c, c->d_iunif, c->d_iconv, k.nv, c->stream))) return rc;
+    if ((rc = run_conv(c, S.iunif, c->d_iconv, k.nv, c->stream))) return rc;
   } else {
-    hipLaunchKernelGGL(k_peak_unity, dim3(k.nv), dim3(256), 0, c->stream, k, c->d_iunif, c->d_iconv,
+    hipLaunchKernelGGL(k_peak_unity, dim3(k.nv), dim3(256), 0, c->stream, k, S.iunif, c->d_iconv,
                        (long long)k.nneed * k.nneed);
   }
-  const size_t ncube = (size_t)k.nv * k.ny * k.nx;
-  double* d_cube = nullptr;
-  HIP_TRY(c, hipMalloc((void**)&d_cube, ncube * sizeof(double)));
   hipLaunchKernelGGL((k_regrid<true>), c->rg_grid, dim3(RED_THREADS), 0, c->stream, k,
-                     c->d_cellx, c->d_fracx, c->d_celly, c->d_fracy, c->d_iconv, c->d_partial,
+                     S.cellx, S.fracx, S.celly, S.fracy, c->d_iconv, S.partial,
                      d_cube);
-  hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, c->stream, k, c->d_partial, c->red_blocks,
-                     (const unsigned char*)nullptr, c->d_stats, (double*)nullptr);
-  hipLaunchKernelGGL(k_scale, dim3(1024), dim3(256), 0, c->stream, d_cube, (long long)ncube, c->d_stats);
+  hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, c->stream, k, S.partial, c->red_blocks,
+                     (const unsigned char*)nullptr, S.stats, (double*)nullptr);
+  hipLaunchKernelGGL(k_scale, dim3(1024), dim3(256), 0, c->stream, d_cube, (long long)ncube, S.stats);
   hipError_t e = hipGetLastError();
   if (e == hipSuccess)
     e = hipMemcpyAsync(out, d_cube, ncube * sizeof(double), hipMemcpyDeviceToHost, c->stream);
   if (e == hipSuccess && stats_out)
-    e = hipMemcpyAsync(stats_out, c->d_stats, 4 * sizeof(double), hipMemcpyDeviceToHost, c->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-  (void)hipFree(d_cube);
-  if (e != hipSuccess) return fail(c, SLAMHIP_ERR_HIP, "cubemodel: %s", hipGetErrorString(e));
+    e = hipMemcpyAsync(stats_out, S.stats, 4 * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+  return single_finish(c, e, "cubemodel");
+}
+
+// k_prep alone for one parameter vector, its WalkerK copied back.
+static int prep_only(slamhip_ctx* c, WalkerK* hw) {
+  Scratch& S = c->own;
+  FitK k = c->k;
+  k.tk = S.tk;
+  hipLaunchKernelGGL(k_prep, dim3(1), dim3(256), 0, c->stream, k, S.params, 1, S.wk,
+                     S.cellx, S.fracx, S.celly, S.fracy, S.tile_ix,
+                     S.tile_jy, (int)c->fz_grid.x, (int)c->fz_grid.y, c->fz_sx, c->fz_sy,
+                     (unsigned char*)nullptr, 0, (int*)nullptr);
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipMemcpyAsync(hw, S.wk, sizeof *hw, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
   return SLAMHIP_OK;
 }
 
@@ -3009,27 +3129,21 @@ int slamhip_surface(slamhip_ctx* c, const double* params, int slot, double* x_ou
   if (rc) return rc;
   if (slot < 0 || slot > 3 || !x_out || !v_out) return fail(c, SLAMHIP_ERR_ARG, "surface: bad arguments");
   const FitK& k = c->k;
-  hipLaunchKernelGGL(k_prep, dim3(1), dim3(256), 0, c->stream, k, c->d_params, 1, c->d_wk,
-                     c->d_cellx, c->d_fracx, c->d_celly, c->d_fracy, c->d_tile_ix,
-                     c->d_tile_jy, (int)c->fz_grid.x, (int)c->fz_grid.y, c->fz_sx, c->fz_sy,
-                     (unsigned char*)nullptr, 0, (int*)nullptr);
   WalkerK hw;
-  HIP_TRY(c, hipMemcpyAsync(&hw, c->d_wk, sizeof hw, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if ((rc = prep_only(c, &hw))) return rc;
   const int s = hw.slot_surf[slot];
-  if (s < 0) return 1;
+  if (s < 0) { (void)scratch_release(c, c->own, c->stream); return 1; }
   const size_t ngrid = (size_t)k.nlayer * k.npix * k.npix;
-  double* d_buf = nullptr;
+  double* d_buf = nullptr;               // parity tap, not a data path: its buffer lives for the call
   HIP_TRY(c, hipMalloc((void**)&d_buf, 2 * ngrid * sizeof(double)));
   hipLaunchKernelGGL(k_surface_tap, dim3((unsigned)((ngrid + 255) / 256)), dim3(256), 0, c->stream,
-                     k, c->d_wk, s, d_buf, d_buf + ngrid);
+                     k, c->own.wk, s, d_buf, d_buf + ngrid);
   hipError_t e = hipGetLastError();
   if (e == hipSuccess) e = hipMemcpyAsync(x_out, d_buf, ngrid * sizeof(double), hipMemcpyDeviceToHost, c->stream);
   if (e == hipSuccess) e = hipMemcpyAsync(v_out, d_buf + ngrid, ngrid * sizeof(double), hipMemcpyDeviceToHost, c->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  rc = single_finish(c, e, "surface");
   (void)hipFree(d_buf);
-  if (e != hipSuccess) return fail(c, SLAMHIP_ERR_HIP, "surface: %s", hipGetErrorString(e));
-  return SLAMHIP_OK;
+  return rc;
 }
 
 int slamhip_prof(slamhip_ctx* c, double cs, double* prof_out, double* prof_d_out) {
@@ -3037,13 +3151,9 @@ int slamhip_prof(slamhip_ctx* c, double cs, double* prof_out, double* prof_d_out
   double p[NP] = {1, 1, cs, 0, -1, 0, 0, 0, 0, 0, 0, 0, 0};
   int rc = single_prepare(c, p);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_prep, dim3(1), dim3(256), 0, c->stream, c->k, c->d_params, 1, c->d_wk,
-                     c->d_cellx, c->d_fracx, c->d_celly, c->d_fracy, c->d_tile_ix,
-                     c->d_tile_jy, (int)c->fz_grid.x, (int)c->fz_grid.y, c->fz_sx, c->fz_sy,
-                     (unsigned char*)nullptr, 0, (int*)nullptr);
   WalkerK hw;
-  HIP_TRY(c, hipMemcpyAsync(&hw, c->d_wk, sizeof hw, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if ((rc = prep_only(c, &hw))) return rc;
+  (void)scratch_release(c, c->own, c->stream);
   if (prof_out) std::memcpy(prof_out, hw.prof, sizeof hw.prof);
   if (prof_d_out) *prof_d_out = hw.prof_d;
   return SLAMHIP_OK;

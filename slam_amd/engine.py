@@ -150,7 +150,9 @@ class HipLikelihood:
 
     def chi2_batch_torch(self, P, out=None, stream=None):
         """Same, for a float64 CUDA tensor P[nw, 13]; enqueued on torch's
-        current stream (or `stream`), returns a CUDA tensor without syncing."""
+        current stream (or `stream`), returns a CUDA tensor without syncing.
+        Calls on one engine must come from one host thread at a time; the
+        library orders them on the device whatever streams they use."""
         import torch
         if not (P.is_cuda and P.dtype == torch.float64 and P.dim() == 2
                 and P.shape[1] == _lib.NPARAM):

@@ -185,6 +185,9 @@ def test_c3_properties():
                        sigma=fit.sigma, pa=2.0, incl=60.0, rmax=synth.RMAX, signmajor=1,
                        signminor=1)
     np.testing.assert_allclose(got[5], orc.chi2_of(s, P[5]), rtol=1e-9)
+    # the cube's truth comes from this package's own cubemodel (synth.make_fit): its
+    # chi2 is checked against the oracle too, so that the property is not self-referential
+    np.testing.assert_allclose(c_truth, orc.chi2_of(s, truth[0]), rtol=1e-9)
     fit.close()
 
 
@@ -253,4 +256,96 @@ def test_wide_velocity_gap_uses_exact_index_path():
     orc.cubemodel(s, P[0], stages=st)
     assert np.array_equal(g != 0, st['Iunif'] != 0)
     assert _golden.relmax(g, st['Iunif']) < 1e-12
+    fit.close()
+
+
+def test_empty_model_with_nan_data_follows_reference():
+    """ff == 0 is tested before anything else (:489): an empty model (every
+    sample masked by Rin) has scale 0 whatever gf is, so with a NaN in the cube
+    chi2 = nansum(data^2)/sigma^2/pixperbeam, not the 0 of an all-NaN model."""
+    from slam_amd import HipLikelihood
+    g = _golden.load('F')
+    kw = _golden.inputs(g)
+    kw['data'] = kw['data'].copy()
+    kw['data'][3, 5, 7] = np.nan
+    s = orc.make_setup(**kw)
+    p_lit = g['vec_deep_p']
+    p_empty = p_lit.copy()
+    p_empty[6] = 1e6                              # Rin beyond the grid
+    expect = np.nansum(kw['data']**2) / s['sigma']**2 / s['pixperbeam']
+    np.testing.assert_allclose(orc.chi2_of(s, p_empty), expect, rtol=1e-14)
+    d = dict(s)
+    d['vunit'] = orc.VUNIT
+    with HipLikelihood(d) as eng:
+        got = eng.chi2_batch(np.array([p_empty, p_lit, p_empty]))
+    np.testing.assert_allclose(got[[0, 2]], expect, rtol=1e-12)
+    assert got[1] == 0.0 == orc.chi2_of(s, p_lit)
+    # the same without the NaN
+    s2 = orc.make_setup(**_golden.inputs(g))
+    d2 = dict(s2)
+    d2['vunit'] = orc.VUNIT
+    with HipLikelihood(d2) as eng:
+        np.testing.assert_allclose(eng.chi2_batch(p_empty[None])[0], orc.chi2_of(s2, p_empty), rtol=1e-12)
+
+
+def test_calls_on_different_streams_are_ordered(c2):
+    """Every entry point of a context works in one scratch set: a batch enqueued
+    on a side stream and not waited for, followed at once by calls on the
+    context's own stream, must give the serial results."""
+    import torch
+    from slam_amd import synth
+    eng = c2.engine
+    P = synth.walkers(192, seed=11)
+    ref = eng.chi2_batch(P)
+    cube = eng.cubemodel(P[3])
+    Pd = torch.as_tensor(P, device='cuda')
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    for _ in range(3):
+        with torch.cuda.stream(side):
+            out1 = eng.chi2_batch_torch(Pd)       # side stream, not waited for
+        got2 = eng.chi2_batch(P[::-1])            # context stream, at once
+        with torch.cuda.stream(side):
+            out3 = eng.chi2_batch_torch(Pd)
+        cube2 = eng.cubemodel(P[3])               # single-vector product in the same scratch
+        side.synchronize()
+        assert np.array_equal(out1.cpu().numpy(), ref)
+        assert np.array_equal(got2, ref[::-1])
+        assert np.array_equal(out3.cpu().numpy(), ref)
+        assert np.array_equal(cube2, cube)
+
+
+@pytest.mark.timeout(1100)
+def test_c4_full_size():
+    """BASELINE config 4 at full size: 1024x1024x256 cube, K = 77 beam (32-row
+    conv windows), 4096 walkers.  Batch order and split are bitwise immaterial,
+    the truth beats every walker, and one walker is checked against the oracle
+    (channel-chunked to bound its memory: ~2 minutes of one host core)."""
+    from slam_amd import synth
+    fit = synth.make_fit('C4')
+    eng = fit.engine
+    assert eng.nv == 256 and eng.nx == eng.ny == 1024 and fit.gaussbeam.shape == (77, 77)
+    assert eng.separable_beam and eng.beam_rank == 1
+    assert 1 <= eng.walkers_per_group <= 128
+    P = synth.walkers(4096)
+    got = fit.chi2_batch(P)
+    assert np.all(np.isfinite(got)) and np.all(got > 0)
+    sub = np.random.default_rng(1).permutation(4096)[:300]
+    assert np.array_equal(fit.chi2_batch(P[sub]), got[sub])
+    assert np.array_equal(np.concatenate([fit.chi2_batch(P[:11]), fit.chi2_batch(P[11:64])]), got[:64])
+    truth = np.array([[synth.TRUTH[k] for k in fit.paramkeys]])
+    c_truth = fit.chi2_batch(truth)[0]
+    assert c_truth < got.min()
+    nbeam = fit.data_valid.size / fit.pixperbeam
+    assert 0.8 * nbeam < c_truth < 1.2 * nbeam
+    s = orc.make_setup(fit.x, fit.y, fit.v, fit.data, bmaj=fit.bmaj, bmin=fit.bmin, bpa=fit.bpa,
+                       sigma=fit.sigma, pa=2.0, incl=60.0, rmax=synth.RMAX, signmajor=1,
+                       signminor=1)
+    i = 7
+    st = {}
+    model = orc.cubemodel(s, P[i], stages=st, kchunk=16)
+    np.testing.assert_allclose(got[i], orc.chi2(s, model), rtol=1e-9)
+    gst = eng.chi2_stats(P[i][None])
+    np.testing.assert_allclose(gst['gf'][0], st['gf'], rtol=1e-9)
+    np.testing.assert_allclose(gst['ff'][0], st['ff'], rtol=1e-9)
     fit.close()
