@@ -105,6 +105,30 @@ int slamhip_chi2_batch(slamhip_ctx* ctx, const double* params, int nw,
 int slamhip_chi2_batch_dev(slamhip_ctx* ctx, const double* params_dev, int nw,
                            double* chi2_dev, void* stream);
 
+/* Allocation-free variant of slamhip_chi2_batch_dev.  It has NO counterpart in
+ * the reference: it is for callers that cannot call hipMalloc -- code under
+ * HIP graph capture, tight serving loops, harnesses that forbid allocation.
+ * Same arguments, same results (bitwise), same kernels; the per-group scratch
+ * (geometry, sparse Iunif tiles, window list, partial sums) lives in a static
+ * device array of SLAMHIP_STATIC_SCRATCH_BYTES that each GPU the library runs
+ * on holds until the process ends, instead of the context's allocation.  The
+ * call issues no hipMalloc/hipFree, creates no events and takes as many walkers
+ * per launch group as fit the array (slamhip_static_info).
+ * Limits: scaling 'uniform' on the fused path only (mom0decon == NULL, conv
+ * modes 0 and 2); a fit that needs more than the array for ONE walker
+ * (roughly 8*nv*nneed^2 + 64*2.5*npix^2 bytes: cubes up to about 256x256x64)
+ * is rejected with SLAMHIP_ERR_NOMEM and a message naming both sizes.
+ * All contexts on one GPU share the array and it keeps the last call's
+ * contents (every launch group re-initialises what it reads): calls that overlap
+ * on one GPU -- from any context, on any stream -- race; order them yourself. */
+#define SLAMHIP_STATIC_SCRATCH_BYTES (64ull << 20)
+int slamhip_chi2_batch_static(slamhip_ctx* ctx, const double* params_dev, int nw,
+                              double* chi2_dev, void* stream);
+/* Size of the static array, bytes one walker of this fit needs in it, walkers
+ * per launch group of slamhip_chi2_batch_static (0: the fit does not fit). */
+int slamhip_static_info(slamhip_ctx* ctx, int64_t* scratch_bytes,
+                        int64_t* bytes_per_walker, int32_t* walkers_per_group);
+
 /* Hot path with its intermediate sums exposed (parity tap for get_scale,
  * :485-490): per walker {gf, ff, scale, chi2, non-empty tiles, tiles}.
  * `params` [nw][13], `stats_out` [nw][6] are host pointers. Synchronous. */

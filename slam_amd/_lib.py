@@ -44,6 +44,10 @@ SYMBOLS = {
     'slamhip_chi2_batch': (C.c_int, [C.c_void_p, _dp, C.c_int, _dp]),
     'slamhip_chi2_batch_dev': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int,
                                           C.c_void_p, C.c_void_p]),
+    'slamhip_chi2_batch_static': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int,
+                                             C.c_void_p, C.c_void_p]),
+    'slamhip_static_info': (C.c_int, [C.c_void_p, C.POINTER(C.c_int64),
+                                      C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
     'slamhip_chi2_stats': (C.c_int, [C.c_void_p, _dp, C.c_int, _dp]),
     'slamhip_cubemodel': (C.c_int, [C.c_void_p, _dp, C.c_int, _dp, _dp]),
     'slamhip_iunif': (C.c_int, [C.c_void_p, _dp, _dp]),

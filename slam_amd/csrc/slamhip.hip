@@ -29,6 +29,7 @@
 #include <cstdio>
 #include <cstring>
 #include <limits>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -1993,9 +1994,19 @@ __global__ void k_scale(double* __restrict__ cube, long long n,
 // ===========================================================================
 // Host side
 // ===========================================================================
+// Scratch of the allocation-free entry point slamhip_chi2_batch_static: every GPU
+// the library runs on holds its own copy of this array, at its own address,
+// until the process ends.  In host code the array's name is only a handle for
+// hipGetSymbolAddress: slamhip_create asks each device once for the address of
+// its copy (static_scratch below) and everything else -- kernel arguments,
+// carving -- goes through that pointer.
+constexpr size_t STATIC_SCRATCH_BYTES = SLAMHIP_STATIC_SCRATCH_BYTES;
+static __device__ __align__(256) unsigned char scratch[STATIC_SCRATCH_BYTES];
+
 // Device scratch of one launch group: everything k_prep .. k_finalize write for
 // up to `wgroup` walkers.  A context owns one set, carved from a single device
-// allocation.
+// allocation; the allocation-free entry point (slamhip_chi2_batch_static) carves
+// a second one out of the library's static device array.
 struct Scratch {
   int wgroup = 0;              // walkers per launch group
   WalkerK* wk = nullptr;
@@ -2031,6 +2042,8 @@ struct slamhip_ctx {
   std::vector<void*> allocs;
   int wgroup = 0;          // walkers per launch group of `own`
   Scratch own;             // per-group scratch, one allocation
+  Scratch fixed;           // the same layout inside the static device array (wgroup 0: the fit does not fit)
+  size_t fixed_need1 = 0;  // bytes one walker of this fit needs there
   size_t max_blocks = 0;   // partial-sum slots per walker
   double* d_stage_p = nullptr;   // slamhip_chi2_batch: parameter / chi2 staging, grown on demand
   double* d_stage_c = nullptr;
@@ -2131,6 +2144,26 @@ int dev_upload(slamhip_ctx* c, const T** p, const T* host, size_t count) {
   if (rc) return rc;
   HIP_TRY(c, hipMemcpy(q, host, count * sizeof(T), hipMemcpyHostToDevice));
   *p = q;
+  return SLAMHIP_OK;
+}
+
+// Address of the current device's copy of `scratch` (asked for once per device).
+constexpr int MAX_DEVICES = 64;
+std::mutex g_static_mu;
+unsigned char* g_static_ptr[MAX_DEVICES];
+
+int static_scratch(slamhip_ctx* c, unsigned char** out) {
+  if (c->device < 0 || c->device >= MAX_DEVICES)
+    return fail(c, SLAMHIP_ERR_ARG, "device index %d beyond %d", c->device, MAX_DEVICES);
+  std::lock_guard<std::mutex> lock(g_static_mu);
+  if (!g_static_ptr[c->device]) {
+    void* p = nullptr;
+    HIP_TRY(c, hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+    if (!p || (reinterpret_cast<uintptr_t>(p) & 255u))
+      return fail(c, SLAMHIP_ERR_HIP, "static scratch: bad device address %p", p);
+    g_static_ptr[c->device] = static_cast<unsigned char*>(p);
+  }
+  *out = g_static_ptr[c->device];
   return SLAMHIP_OK;
 }
 
@@ -2842,6 +2875,20 @@ int slamhip_create(const slamhip_desc* d, slamhip_ctx** out) {
     const int per_cu_d = std::max(1, (int)((160 * 1024) / std::max<size_t>(c->fz_lds_direct + 2048, 1)));
     c->persist_direct = prop.multiProcessorCount * std::min(per_cu_d, 8);
   }
+  // --- the allocation-free entry point's scratch set: the same layout inside this
+  //     GPU's copy of the static device array, for as many walkers as fit
+  {
+    unsigned char* sp = nullptr;
+    if ((rc = static_scratch(c, &sp))) return rc;
+    c->fixed_need1 = carve(c, 1, nullptr, nullptr);
+    int wf = 0;
+    if (c->fused && !d->mom0decon) {
+      wf = (int)std::min<size_t>(W, STATIC_SCRATCH_BYTES / c->fixed_need1);
+      while (wf > 0 && carve(c, wf, nullptr, nullptr) > STATIC_SCRATCH_BYTES) --wf;
+    }
+    if (wf > 0) carve(c, wf, sp, &c->fixed);
+    c->fixed.wgroup = wf;
+  }
   HIP_TRY(c, hipStreamCreate(&c->stream));
   if (d->mom0decon && c->ob_ty) {
     // residual sum of every (channel, tile) when the model is zero there: this
@@ -2974,6 +3021,35 @@ int slamhip_chi2_batch_dev(slamhip_ctx* c, const double* params_dev, int nw,
   if (nw == 0) return SLAMHIP_OK;
   HIP_TRY(c, hipSetDevice(c->device));
   return batch_on(c, c->own, params_dev, nw, chi2_dev, static_cast<hipStream_t>(stream));
+}
+
+int slamhip_chi2_batch_static(slamhip_ctx* c, const double* params_dev, int nw,
+                              double* chi2_dev, void* stream) {
+  if (!c || c->wgroup < 1) return SLAMHIP_ERR_STATE;
+  if (nw < 0 || (nw > 0 && (!params_dev || !chi2_dev)))
+    return fail(c, SLAMHIP_ERR_ARG, "chi2_batch_static: bad arguments");
+  if (c->k.mom0decon || !c->fused || c->conv_mode == 1)
+    return fail(c, SLAMHIP_ERR_ARG, "chi2_batch_static: only the fused scaling='uniform' path "
+                                    "(conv modes 0 and 2) runs from the static scratch");
+  if (c->fixed.wgroup < 1)
+    return fail(c, SLAMHIP_ERR_NOMEM,
+                "chi2_batch_static: one walker of this fit needs %zu bytes of scratch, the "
+                "static scratch holds %zu (SLAMHIP_STATIC_SCRATCH_BYTES)",
+                c->fixed_need1, (size_t)STATIC_SCRATCH_BYTES);
+  if (nw == 0) return SLAMHIP_OK;
+  HIP_TRY(c, hipSetDevice(c->device));
+  // no event bookkeeping here (the set has no event): calls that overlap on one
+  // GPU race, as the header says
+  return batch_on(c, c->fixed, params_dev, nw, chi2_dev, static_cast<hipStream_t>(stream));
+}
+
+int slamhip_static_info(slamhip_ctx* c, int64_t* scratch_bytes, int64_t* bytes_per_walker,
+                        int32_t* walkers_per_group) {
+  if (!c) return SLAMHIP_ERR_ARG;
+  if (scratch_bytes) *scratch_bytes = (int64_t)STATIC_SCRATCH_BYTES;
+  if (bytes_per_walker) *bytes_per_walker = (int64_t)c->fixed_need1;
+  if (walkers_per_group) *walkers_per_group = c->fixed.wgroup;
+  return SLAMHIP_OK;
 }
 
 int slamhip_chi2_batch(slamhip_ctx* c, const double* params, int nw, double* chi2_out) {

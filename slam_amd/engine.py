@@ -167,6 +167,31 @@ class HipLikelihood:
             'chi2_batch_dev')
         return out
 
+    def chi2_batch_static_torch(self, P, out=None, stream=None):
+        """`chi2_batch_torch` through slamhip_chi2_batch_static: same kernels and
+        results, scratch in the library's static device array (no allocation
+        inside the call; `out` should be passed by callers that cannot allocate)."""
+        import torch
+        if not (P.is_cuda and P.dtype == torch.float64 and P.dim() == 2
+                and P.shape[1] == _lib.NPARAM and P.is_contiguous()):
+            raise ValueError('P must be a contiguous float64 CUDA tensor [nw, 13]')
+        if out is None:
+            out = torch.empty(P.shape[0], dtype=torch.float64, device=P.device)
+        st = stream if stream is not None else torch.cuda.current_stream(P.device)
+        self._check(self._lib.slamhip_chi2_batch_static(
+            self._ctx, C.c_void_p(P.data_ptr()), P.shape[0],
+            C.c_void_p(out.data_ptr()), C.c_void_p(st.cuda_stream)),
+            'chi2_batch_static')
+        return out
+
+    def static_info(self):
+        """(bytes of the static scratch, bytes one walker needs, walkers per
+        launch group of the allocation-free entry point; 0 = does not fit)."""
+        a, b, w = C.c_int64(), C.c_int64(), C.c_int32()
+        self._check(self._lib.slamhip_static_info(self._ctx, C.byref(a), C.byref(b),
+                                                  C.byref(w)), 'static_info')
+        return a.value, b.value, w.value
+
     # -- single-vector products / parity taps ------------------------------
     def cubemodel(self, p, convolving=True, return_stats=False):
         a = self._params(p, False)
