@@ -23,6 +23,9 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK = 8.0e12      # B/s, MI355X spec (MI355X_MICROARCH.md, chip-level parameters)
+# FP64 vector peak: half of the guide's 157.3 TFLOP/s FP32 vector peak (a wave64 FP64 FMA issues in
+# 4 cycles on a SIMD-32, an FP32 one in 2): 256 CUs x 4 SIMDs x 16 FMA/clk x 2 flop x 2.4 GHz
+FP64_PEAK = 78.6e12
 
 
 def main():
@@ -37,6 +40,9 @@ def main():
     ap.add_argument('--bpa', type=float, default=0.0, help='beam position angle [deg]; 0 = separable')
     ap.add_argument('--scaling', default='uniform', choices=['uniform', 'mom0ft', 'mom0clean'],
                     help="ChannelFit scaling (C2-C4); the headline metric is 'uniform'")
+    ap.add_argument('--workload', default='sparse', choices=['sparse', 'dense_disk', 'envelope'],
+                    help="walker set (slam_amd/synth.py): 'sparse' = the headline (example priors); "
+                         "'dense_disk' / 'envelope' light most of the sky")
     ap.add_argument('--cpu-evals', type=int, default=1,
                     help='oracle evaluations timed for cpu_baseline (0 = skip)')
     ap.add_argument('--cpu-procs', type=int, default=-1,
@@ -78,10 +84,11 @@ def main():
         if world > 1:
             dist.destroy_process_group()
         return
-    fit = synth.make_fit(args.config, bpa=args.bpa, scaling=args.scaling)
+    fit = synth.make_fit(args.config, bpa=args.bpa, scaling=args.scaling,
+                         envelope=args.workload == 'envelope')
     eng = fit.engine
     nw_total = args.walkers * world
-    P = synth.walkers(nw_total) if rank == 0 else None
+    P = synth.walkers(nw_total, workload=args.workload) if rank == 0 else None
     sharded = ShardedLikelihood(eng.chi2_batch_torch, device='cuda')
     Pd = torch.as_tensor(P, device='cuda') if rank == 0 else None
 
@@ -93,13 +100,11 @@ def main():
     for _ in range(args.warmup):
         chi2 = sharded.chi2(Pd, nw_total)
     barrier()
-    eng.profile_begin()
-    t0 = time.perf_counter()
+    t0 = time.perf_counter()                    # the headline: nothing but the K steps in here
     for _ in range(args.steps):
         chi2 = sharded.chi2(Pd, nw_total)
     barrier()
     dt = time.perf_counter() - t0
-    kern = eng.profile_end()
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device='cuda')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -107,66 +112,27 @@ def main():
     chi2 = chi2.cpu().numpy()
 
     if rank == 0:
-        B = 8
-        nv, n, nx, ny = eng.nv, eng.nneed, eng.nx, eng.ny
-        bytes_eval = synth.bytes_per_eval(fit, B)
-        # algorithmic bytes per walker of each kernel (SURVEY.md 8d's four stages)
-        alg = {'k_profile': B * nv * n * n,
-               'k_conv': 2 * B * nv * n * n,
-               'k_regrid': B * nv * (n * n + nx * ny)}
-        if args.scaling != 'uniform':
-            # mom0 scalings: regrid+scale reads Iunif, writes and re-reads the observed cube;
-            # the beam pass reads it and the data once more
-            alg['k_regrid'] = B * nv * (n * n + 3 * nx * ny)
-            alg['k_conv'] = 2 * B * nv * nx * ny
-        elif kern.get('k_regrid', (0, 0))[1] == 0:
-            # fused hot path: k_conv (= k_conv_chi2) performs the conv AND the
-            # regrid + chi-square stages, the convolved cube never reaches HBM
-            alg['k_conv'] += alg.pop('k_regrid')
-        evals_rank = args.walkers * args.steps
-        total_ms = sum(v[0] for v in kern.values())
-        per_kernel = {}
-        for name, (ms, cnt) in kern.items():
-            if cnt == 0:
-                continue
-            d = {'ms_per_launch': ms / cnt, 'launches': cnt, 'ms_per_eval': ms / evals_rank,
-                 'share': ms / total_ms}
-            if name in alg:
-                d['achieved_GBps'] = alg[name] * evals_rank / (ms * 1e-3) / 1e9
-                d['frac'] = d['achieved_GBps'] * 1e9 / HBM_PEAK
-            per_kernel[name] = d
-        dom = max(alg, key=lambda k: kern.get(k, (0, 0))[0])
-        ms, cnt = kern[dom]
-        achieved = alg[dom] * evals_rank / (ms * 1e-3)
-        traffic, traffic_note = measured_traffic(dom, args, eng)
-        roofline = {
-            'bound': 'hbm', 'kernel': dom,
-            'achieved': achieved / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
-            'frac': achieved / HBM_PEAK, 'traffic': traffic, 'traffic_source': traffic_note,
-            'bytes_per_launch': alg[dom] * evals_rank / cnt,
-            'ms_per_launch': ms / cnt, 'launches': cnt,
-            'pipeline': {'bytes_per_eval': bytes_eval,
-                         'achieved': bytes_eval * evals_rank / dt / 1e9,
-                         'frac': bytes_eval * evals_rank / dt / HBM_PEAK,
-                         'kernel_ms_per_eval': total_ms / evals_rank},
-            'per_kernel': per_kernel,
-        }
-        out = {
-            'metric': 'walker chi2 evals/sec (whole node) at 512x512x128'
-                      if args.config == 'C3' and args.scaling == 'uniform'
-                      else f'walker chi2 evals/sec (whole node), {args.config} scaling={args.scaling}',
-            'value': nw_total * args.steps / dt, 'unit': 'evals/s',
-            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': f'SYN-v1 {args.config}: {nx}x{ny}x{nv} cube, '
-                                   f'{args.walkers} walkers per GPU per step, beam K={fit.gaussbeam.shape[0]} '
-                                   f'bpa={args.bpa:g} (beam rank {eng.beam_rank})',
-                       'walkers_per_gpu': args.walkers, 'walkers_per_launch': eng.walkers_per_group,
-                       'npix': eng.npix, 'nneed': n, 'nleaf': eng.nleaf,
-                       'chi2_checksum': float(np.sum(chi2))},
-            'roofline': roofline,
-        }
+        # per-kernel durations: a pass of its own (HIP events around every launch,
+        # on the launch stream), outside the timed region
+        mine = Pd[:args.walkers].contiguous()
+        psteps = max(1, min(args.steps, 3))
+        eng.profile_begin()
+        for _ in range(psteps):
+            eng.chi2_batch_torch(mine)
+        torch.cuda.synchronize()
+        kern = eng.profile_end()
+        counts = None
+        if args.scaling == 'uniform':
+            # one launch group on its own, then what it touched and computed
+            wl = min(eng.walkers_per_group, args.walkers)
+            eng.chi2_batch_torch(mine[:wl].contiguous())
+            torch.cuda.synchronize()
+            try:
+                counts = eng.group_counts(wl)
+                counts['walkers'] = wl
+            except Exception as e:              # dense conv mode etc.: no accounting
+                counts = None
+        out = report(args, fit, eng, world, nw_total, dt, chi2, kern, psteps, counts)
         if world == 1 and args.cpu_evals > 0:
             out['cpu_baseline'] = cpu_baseline(fit, P, chi2, args.cpu_evals)
             if multi is not None:
@@ -174,6 +140,122 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def kernel_model(eng, fit, counts, itemsize=8):
+    """Per launch group: the bytes each hot kernel MUST move in this design and the
+    FP64 lane-operations it executes, from slamhip_group_counts.
+    Tiles are 32x8 pixels; a geometry entry is {vlos, weight} = 2 values."""
+    B = itemsize
+    W = counts['walkers']
+    K = fit.gaussbeam.shape[0]
+    kpad = (K + 7) // 8 * 8
+    ty = 64 if (63 + kpad)**2 * 8 + 16 * kpad <= 156 * 1024 else 32   # conv window rows (as slamhip_create picks)
+    nslot = eng.nleaf                          # >= samples; padding ignored
+    tile = 32 * 8 * B
+    geom = counts['geom_groups'] * 64 * 2 * B
+    by = {
+        # reads each sample's coordinates once per 8 walkers, writes the stored entries + flag words
+        'k_surface': -(-W // 8) * nslot * (4 + 2 * 8) + geom + W * (nslot // 64) * 4,
+        # reads the stored entries (once: the channel blocks of a tile share an L2), writes lit tiles + flags
+        'k_profile': geom + counts['lit_planes'] * (tile + 1),
+        # reads every lit tile once, the data under every live window, its descriptor
+        'k_conv': counts['lit_planes'] * tile + counts['live_windows'] * (63 * (ty - 1) * 8 + 240),
+    }
+    fl = {
+        # table lookups: 16 channels x (index add + multiply-add) per hit
+        'k_profile': counts['profile_hits'] * 16 * 3,
+        # row pass over rows with emission, column pass over executed 8x8 tap blocks, 64 lanes each
+        'k_conv': 2 * 64 * (counts['window_rows'] * kpad + counts['col_blocks'] * 64),
+    }
+    if eng.beam_rank == 0:
+        # direct K x K taps in the fused kernel: every output of a live window takes K x kpad multiply-adds
+        fl['k_conv'] = 2 * counts['live_windows'] * 64 * ty * K * kpad
+    return by, fl
+
+
+def report(args, fit, eng, world, nw_total, dt, chi2, kern, psteps, counts):
+    B = 8
+    nv, n, nx, ny = eng.nv, eng.nneed, eng.nx, eng.ny
+    bytes_eval = synth_bytes_per_eval(eng, B)
+    # SURVEY.md 8d's DENSE algorithmic bytes per walker of each kernel (four stages)
+    dense = {'k_profile': B * nv * n * n,
+             'k_conv': 2 * B * nv * n * n,
+             'k_regrid': B * nv * (n * n + nx * ny)}
+    if args.scaling != 'uniform':
+        dense['k_regrid'] = B * nv * (n * n + 3 * nx * ny)
+        dense['k_conv'] = 2 * B * nv * nx * ny
+    elif kern.get('k_regrid', (0, 0))[1] == 0:
+        dense['k_conv'] += dense.pop('k_regrid')       # fused: conv + regrid + chi2 in one kernel
+    evals_prof = args.walkers * psteps
+    total_ms = sum(v[0] for v in kern.values())
+    model_b, model_f = kernel_model(eng, fit, counts) if counts else ({}, {})
+    groups = -(-args.walkers // eng.walkers_per_group)          # launch groups per step
+    per_kernel = {}
+    for name, (ms, cnt) in kern.items():
+        if cnt == 0:
+            continue
+        d = {'ms_per_launch': ms / cnt, 'launches': cnt, 'ms_per_eval': ms / evals_prof,
+             'share': ms / total_ms}
+        sec = ms * 1e-3 / cnt
+        if name in dense:
+            d['algorithmic_x_peak'] = dense[name] * evals_prof / (ms * 1e-3) / HBM_PEAK
+        if counts and counts['walkers'] == min(eng.walkers_per_group, args.walkers) and groups * psteps == cnt:
+            # the counted group is a typical launch (same walkers per launch)
+            if name in model_b:
+                d['bytes_per_launch'] = model_b[name]
+                d['hbm_GBps'] = model_b[name] / sec / 1e9
+                d['hbm_frac'] = model_b[name] / sec / HBM_PEAK
+            if name in model_f:
+                d['fp64_ops_per_launch'] = model_f[name]
+                d['fp64_TFLOPs'] = model_f[name] / sec / 1e12
+                d['fp64_frac'] = model_f[name] / sec / FP64_PEAK
+        per_kernel[name] = d
+    dom = max((k for k in per_kernel if k in dense), key=lambda k: kern[k][0])
+    dk = per_kernel[dom]
+    traffic, traffic_note = measured_traffic(dom, args, eng)
+    roofline = {'kernel': dom, 'ms_per_launch': dk['ms_per_launch'], 'launches': dk['launches'],
+                'traffic': traffic, 'traffic_source': traffic_note,
+                'algorithmic_x_peak': dk.get('algorithmic_x_peak'),
+                'per_kernel': per_kernel,
+                'pipeline': {'dense_bytes_per_eval': bytes_eval,
+                             'algorithmic_x_peak': bytes_eval * nw_total * args.steps / world / dt / HBM_PEAK,
+                             'kernel_ms_per_eval': total_ms / evals_prof}}
+    if traffic is not None:
+        roofline['traffic_frac'] = traffic / (dk['ms_per_launch'] * 1e-3) / HBM_PEAK
+    if 'fp64_frac' in dk:
+        # the binding resource of this design is the FP64 vector pipe (arithmetic intensity
+        # of the compulsory traffic is above the machine balance): fraction against THAT
+        roofline.update({'bound': 'fp64_valu', 'achieved': dk['fp64_TFLOPs'], 'peak': FP64_PEAK / 1e12,
+                         'unit': 'TFLOP/s', 'frac': dk['fp64_frac'],
+                         'hbm': {'achieved': dk['hbm_GBps'], 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
+                                 'frac': dk['hbm_frac'], 'bytes_per_launch': dk['bytes_per_launch']},
+                         'counts': counts})
+    else:
+        roofline.update({'bound': 'hbm', 'achieved': None, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
+                         'frac': None})
+    return {
+        'metric': 'walker chi2 evals/sec (whole node) at 512x512x128'
+                  if args.config == 'C3' and args.scaling == 'uniform' and args.workload == 'sparse'
+                  else f'walker chi2 evals/sec (whole node), {args.config} scaling={args.scaling} '
+                       f'workload={args.workload}',
+        'value': nw_total * args.steps / dt, 'unit': 'evals/s',
+        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True,
+        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+        'config': {'workload': f'SYN-v1 {args.config} ({args.workload}): {nx}x{ny}x{nv} cube, '
+                               f'{args.walkers} walkers per GPU per step, beam K={fit.gaussbeam.shape[0]} '
+                               f'bpa={args.bpa:g} (beam rank {eng.beam_rank})',
+                   'walkers_per_gpu': args.walkers, 'walkers_per_launch': eng.walkers_per_group,
+                   'npix': eng.npix, 'nneed': n, 'nleaf': eng.nleaf,
+                   'chi2_checksum': float(np.sum(chi2))},
+        'roofline': roofline,
+    }
+
+
+def synth_bytes_per_eval(e, itemsize=8):
+    """write Iunif; read Iunif + write Iconv; read Iconv + read data."""
+    return itemsize * e.nv * (4 * e.nneed**2 + e.nx * e.ny)
 
 
 def run_pv(args, rank, world, torch, dist):
@@ -198,12 +280,15 @@ def run_pv(args, rank, world, torch, dist):
     for _ in range(args.warmup):
         lnp = sharded.chi2(Qd, nw_total)
     barrier()
-    eng.profile_begin()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         lnp = sharded.chi2(Qd, nw_total)
     barrier()
     dt = time.perf_counter() - t0
+    eng.profile_begin()                         # per-kernel events: a pass of their own
+    for _ in range(args.steps):
+        lnp = sharded.chi2(Qd, nw_total)
+    barrier()
     kern = eng.profile_end()
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device='cuda')
@@ -342,13 +427,13 @@ def measured_traffic(kernel, args, eng):
     kernels of known size is in DESIGN.md).  bench.py itself cannot read the
     counters, so this is the figure of the profiled run of the same command;
     null if no matching profile is committed."""
-    path = os.path.join(ROOT, 'profiles', 'r1_traffic.json')
+    path = os.path.join(ROOT, 'profiles', 'r2_traffic.json')
     try:
         t = json.load(open(path))
     except Exception:
         return None, None
     meta = t.get('_meta', {})
-    if args.scaling != 'uniform':
+    if args.scaling != 'uniform' or args.workload != 'sparse':
         return None, None
     if (meta.get('config') != args.config or meta.get('walkers_per_launch') != eng.walkers_per_group
             or meta.get('bpa') != args.bpa):
@@ -358,7 +443,7 @@ def measured_traffic(kernel, args, eng):
     for k, v in t.items():
         if k.startswith(names.get(kernel, kernel)):
             return (2.0 * v['fetch_bytes_per_launch_max'] + v['write_bytes_per_launch_max'],
-                    'profiles/r1_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, max over launches)')
+                    'profiles/r2_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 / WRITE_SIZE, separate passes, max over launches)')
     return None, None
 
 

@@ -183,6 +183,17 @@ const char* slamhip_kernel_name(int i);
 int slamhip_profile_begin(slamhip_ctx* ctx);
 int slamhip_profile_end(slamhip_ctx* ctx, double* total_ms, int64_t* launches);
 
+/* Measurement aid (no counterpart in the reference): what the context's LAST
+ * launch group of `nw` walkers (fused scaling='uniform' path) touched and
+ * computed, counted from the scratch it left: out[0] live conv windows,
+ * [1] occupied 32x8 Iunif tiles under them (halo included), [2] window rows with
+ * emission, [3] column-pass tap blocks executed, [4] lit (tile, channel) planes
+ * of Iunif, [5] stored geometry groups (64 samples x surface), [6] k_profile
+ * hits (lane, sample, surface, 16-channel block), [7] the same per 64-sample
+ * wave (at least one lane hit).  bench.py prices the
+ * kernels' compulsory bytes and useful FP64 operations from these. */
+int slamhip_group_counts(slamhip_ctx* ctx, int nw, int64_t* out);
+
 const char* slamhip_last_error(slamhip_ctx* ctx);
 void slamhip_destroy(slamhip_ctx* ctx);
 

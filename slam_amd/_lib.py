@@ -62,6 +62,7 @@ SYMBOLS = {
     'slamhip_kernel_name': (C.c_char_p, [C.c_int]),
     'slamhip_profile_begin': (C.c_int, [C.c_void_p]),
     'slamhip_profile_end': (C.c_int, [C.c_void_p, _dp, C.POINTER(C.c_int64)]),
+    'slamhip_group_counts': (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int64)]),
     'slamhip_last_error': (C.c_char_p, [C.c_void_p]),
     'slamhip_destroy': (None, [C.c_void_p]),
     'slamhip_device_count': (C.c_int, []),

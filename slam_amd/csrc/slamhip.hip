@@ -351,7 +351,7 @@ constexpr int SURF_WPT = 8;   // walkers per k_surface thread
 // consecutive 16-B entries for every rank.
 __global__ void __launch_bounds__(256)
 k_surface(FitK g, const WalkerK* __restrict__ wk, double2* __restrict__ geom,
-          unsigned* __restrict__ gflag, int nw) {
+          unsigned* __restrict__ gflag, float2* __restrict__ grange, int nw) {
   const long long leaf = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // slot
   if (leaf >= g.nslot) return;                             // whole waves: nslot is a multiple of 256
   const unsigned code = g.leaf[leaf];
@@ -374,9 +374,13 @@ k_surface(FitK g, const WalkerK* __restrict__ wk, double2* __restrict__ geom,
   // every surface whatever x is (:443-447); a wave of such samples is done here
   const bool beyond = !g.envelope && fabs(Y) > w.Rc * (1.0 + 1e-12);
   if (__ballot(!pad && !beyond) == 0ull) {
-    if ((threadIdx.x & 63) == 0) gflag[(long long)wi * (g.nslot >> 6) + (leaf >> 6)] = 0u;
+    if ((threadIdx.x & 63) == 0) {
+      gflag[(long long)wi * (g.nslot >> 6) + (leaf >> 6)] = 0u;
+      grange[(long long)wi * (g.nslot >> 6) + (leaf >> 6)] = make_float2(3.0e38f, -3.0e38f);
+    }
     continue;
   }
+  float vlo = 3.0e38f, vhi = -3.0e38f;                     // range of the stored vl of this lane
   for (int s = 0; s < w.nsurf; ++s) {
     double xs;
     if (w.kind[s] == 3) {                                  // :392-405, as surface_x
@@ -410,9 +414,23 @@ k_surface(FitK g, const WalkerK* __restrict__ wk, double2* __restrict__ geom,
     if (__ballot(wt != 0.0 && vl != VL_MASKED) != 0ull) {  // wave-uniform
       geom[((long long)wi * 4 + s) * g.nslot + leaf] = make_double2(vl, wt);
       fm |= 1u << s;
+      if (wt != 0.0 && vl != VL_MASKED) {
+        // single precision, widened by more than its rounding: only k_plan's cull reads it
+        const float f = (float)vl, e = fabsf(f) * 2.4e-7f + 1.0e-30f;
+        vlo = fminf(vlo, f - e);
+        vhi = fmaxf(vhi, f + e);
+      }
     }
   }
-  if ((threadIdx.x & 63) == 0) gflag[(long long)wi * (g.nslot >> 6) + (leaf >> 6)] = fm;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    vlo = fminf(vlo, __shfl_xor(vlo, off, 64));
+    vhi = fmaxf(vhi, __shfl_xor(vhi, off, 64));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    gflag[(long long)wi * (g.nslot >> 6) + (leaf >> 6)] = fm;
+    grange[(long long)wi * (g.nslot >> 6) + (leaf >> 6)] = make_float2(vlo, vhi);
+  }
   }
 }
 
@@ -460,6 +478,67 @@ __device__ inline unsigned wave_or(unsigned v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v |= __shfl_xor(v, off, 64);
   return v;
+}
+
+// k_plan: which (walker, 32x8 pixel tile, 16-channel block) triples can hold
+// emission at all.  A thread takes one (walker, tile): the velocity range of
+// the tile's stored samples (k_surface's per-wave ranges) against every channel
+// block's window, exactly the test k_profile applies per sample but on the
+// tile's range, so nothing that could light a block is left out.  The triples
+// that pass are appended to `items` (count in *nitems), a tile's blocks next to
+// each other; the occupancy bytes of all others stay at the zero the launch
+// group's memset left.  Most of the sky is empty in most channels: at the
+// headline workload about one triple in eight is listed.
+__global__ void __launch_bounds__(256)
+k_plan(FitK g, const WalkerK* __restrict__ wk, const float2* __restrict__ grange, int nw, int ntile,
+       uint2* __restrict__ items, int* __restrict__ nitems) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int nchunk = g.nvpad / CH;
+  int wi = 0, tile = 0;
+  float lo = 3.0e38f, hi = -3.0e38f;
+  const bool live = t < nw * ntile;
+  if (live) {
+    wi = t / ntile;
+    tile = t - wi * ntile;
+    const int g0 = g.tile_goff[tile] >> 6, ng = g.tile_nl[tile] * 4;
+    const float2* r = grange + (long long)wi * (g.nslot >> 6) + g0;
+    for (int q = 0; q < ng; ++q) {
+      const float2 v = r[q];
+      lo = fminf(lo, v.x);
+      hi = fmaxf(hi, v.y);
+    }
+  }
+  // items of this thread, counted first, then one slot reservation per wave
+  int mine = 0;
+  double hw = 0.0, voff = 0.0;
+  if (live && lo <= hi) {
+    hw = wk[wi].halfwidth;
+    voff = wk[wi].voff;
+    for (int cix = 0; cix < nchunk; ++cix) {
+      const double cmid = 0.5 * (g.ch_vmin[cix] + g.ch_vmax[cix]);
+      const double hwc = hw + 0.5 * (g.ch_vmax[cix] - g.ch_vmin[cix]);
+      mine += ((double)lo + voff <= cmid + hwc) && ((double)hi + voff >= cmid - hwc);
+    }
+  }
+  const int lane = threadIdx.x & 63;
+  int incl = mine;                                 // inclusive prefix sum over the wave
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int v = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += v;
+  }
+  const int total = __shfl(incl, 63, 64);
+  int base = 0;
+  if (lane == 0 && total) base = atomicAdd(nitems, total);
+  base = __shfl(base, 0, 64) + incl - mine;
+  if (mine) {
+    for (int cix = 0; cix < nchunk; ++cix) {
+      const double cmid = 0.5 * (g.ch_vmin[cix] + g.ch_vmax[cix]);
+      const double hwc = hw + 0.5 * (g.ch_vmax[cix] - g.ch_vmin[cix]);
+      if (((double)lo + voff <= cmid + hwc) && ((double)hi + voff >= cmid - hwc))
+        items[base++] = make_uint2((unsigned)(wi * ntile + tile), (unsigned)cix);
+    }
+  }
 }
 
 // Iunif is sparse (a channel map is mostly empty sky), so each (walker,
@@ -1506,6 +1585,83 @@ k_finalize(FitK g, const double* __restrict__ partial, int nblk,
 
 
 // ---------------------------------------------------------------------------
+// Accounting kernels for bench.py's roofline block (no counterpart in the
+// reference, never on the hot path): what the last launch group actually
+// touched and computed, counted from the scratch it left behind.
+//   cnt[0] live conv windows              cnt[1] occupied Iunif tiles under them (halo included)
+//   cnt[2] window rows with emission      cnt[3] column-pass tap blocks executed
+//   cnt[4] lit (tile, channel) planes     cnt[5] stored geometry groups (64 samples x surface)
+//   cnt[6] k_profile hits: (lane, sample rank, surface, channel block) that passed the velocity cull
+//   cnt[7] the same per wave (64 samples): (wave, surface, channel block) with at least one such lane
+// ---------------------------------------------------------------------------
+__device__ inline void count_add(unsigned long long* dst, unsigned long long v) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  if ((threadIdx.x & 63) == 0 && v) atomicAdd(dst, v);
+}
+
+__global__ void __launch_bounds__(256)
+k_count_windows(const WinDesc* __restrict__ list, const int* __restrict__ count, int ty, int kpad,
+                unsigned long long* __restrict__ cnt) {
+  const int nlive = count[0];
+  unsigned long long nocc = 0, rows = 0, blocks = 0, live = 0;
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < nlive; e += gridDim.x * 256) {
+    const WinDesc& d = list[e];
+    live += 1;
+    nocc += d.nocc;
+    rows += __popcll(d.rowmask[0]) + __popcll(d.rowmask[1]) + __popcll(d.rowmask[2]) + __popcll(d.rowmask[3]);
+    for (int wv = 0; wv < ty / CONV_R; ++wv)
+      for (int u0 = 0; u0 < kpad; u0 += CONV_R) {             // as the column pass of k_conv_chi2
+        const int ra = wv * CONV_R + u0, w0 = ra >> 6, sh = ra & 63;
+        const unsigned long long lo = d.rowmask[w0], hi = w0 < 3 ? d.rowmask[w0 + 1] : 0ull;
+        const unsigned long long bits = (lo >> sh) | (sh ? (hi << (64 - sh)) : 0ull);
+        if (bits & ((1ull << (2 * CONV_R - 1)) - 1ull)) blocks += 1;
+      }
+  }
+  count_add(&cnt[0], live);
+  count_add(&cnt[1], nocc);
+  count_add(&cnt[2], rows);
+  count_add(&cnt[3], blocks);
+}
+
+__global__ void __launch_bounds__(256)
+k_count_flags(const unsigned char* __restrict__ flags, long long nflag,
+              const unsigned* __restrict__ gflag, long long ngflag,
+              unsigned long long* __restrict__ cnt) {
+  unsigned long long lit = 0, groups = 0;
+  const long long stride = (long long)gridDim.x * 256;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < nflag; e += stride) lit += flags[e] != 0;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < ngflag; e += stride) groups += __popc(gflag[e] & 15u);
+  count_add(&cnt[4], lit);
+  count_add(&cnt[5], groups);
+}
+
+__global__ void __launch_bounds__(256)
+k_count_hits(FitK g, const WalkerK* __restrict__ wk, const double2* __restrict__ geom,
+             const unsigned* __restrict__ gflag, int nw, unsigned long long* __restrict__ cnt) {
+  const long long slot = (long long)blockIdx.x * 256 + threadIdx.x;   // nslot is a multiple of 256
+  unsigned long long hits = 0, wavehits = 0;
+  const int nchunk = g.nvpad / CH;
+  for (int wi = 0; wi < nw; ++wi) {
+    const unsigned fm = gflag[(long long)wi * (g.nslot >> 6) + (slot >> 6)];
+    const double hw = wk[wi].halfwidth, voff = wk[wi].voff;
+    for (int s = 0; s < 4; ++s) {
+      if (!((fm >> s) & 1u)) continue;                      // wave-uniform
+      const double o = geom[((long long)wi * 4 + s) * g.nslot + slot].x + voff;
+      for (int cix = 0; cix < nchunk; ++cix) {
+        const double cmid = 0.5 * (g.ch_vmin[cix] + g.ch_vmax[cix]);
+        const double hwc = hw + 0.5 * (g.ch_vmax[cix] - g.ch_vmin[cix]);
+        const bool hit = !(fabs(o - cmid) > hwc);
+        hits += hit;
+        const unsigned long long any = __ballot(hit);          // every lane of the wave takes part
+        wavehits += ((threadIdx.x & 63) == 0 && any != 0ull) ? 1 : 0;
+      }
+    }
+  }
+  count_add(&cnt[6], hits);
+  count_add(&cnt[7], wavehits);
+}
+
+// ---------------------------------------------------------------------------
 // 'mom0*' scalings (:520-532): the UNCONVOLVED cube is regridded first, every
 // pixel's spectrum is rescaled so that its moment 0 equals the deconvolved
 // observed one, and the beam is applied on the observed grid.
@@ -2013,6 +2169,8 @@ struct Scratch {
   double* params = nullptr;
   double2* geom = nullptr;     // [walker][surface][sample] {vlos*sqrt(M), weight}
   unsigned* gflag = nullptr;   // [walker][sample / 64] bit s: surface s of these 64 samples was stored
+  float2* grange = nullptr;    // [walker][sample / 64] range of the stored vlos*sqrt(M) of these 64 samples
+  uint2* items = nullptr;      // k_plan's list: (walker * tiles + tile, channel block) that can hold emission
   double* iunif = nullptr;
   double* partial = nullptr;
   double* stats = nullptr;
@@ -2184,6 +2342,8 @@ size_t carve(const slamhip_ctx* c, size_t W, unsigned char* base, Scratch* s) {
   t.params = reinterpret_cast<double*>(take(W * NP * sizeof(double)));
   t.geom = reinterpret_cast<double2*>(take(W * 4 * (size_t)k.nslot * sizeof(double2)));
   t.gflag = reinterpret_cast<unsigned*>(take(W * (size_t)(k.nslot / 64) * sizeof(unsigned)));
+  t.grange = reinterpret_cast<float2*>(take(W * (size_t)(k.nslot / 64) * sizeof(float2)));
+  t.items = reinterpret_cast<uint2*>(take(W * (size_t)c->ftx * c->fty * (k.nvpad / CH) * sizeof(uint2)));
   t.iunif = reinterpret_cast<double*>(take(W * k.nv * n * n * sizeof(double)));
   t.partial = reinterpret_cast<double*>(take(W * c->max_blocks * 3 * sizeof(double)));
   t.stats = reinterpret_cast<double*>(take(W * 6 * sizeof(double)));
@@ -2387,7 +2547,7 @@ int run_model(slamhip_ctx* c, Scratch& S, const double* d_params, int nw, hipStr
   {
     Timed t_(c, KID_SURFACE, st);
     dim3 g1((unsigned)((k.nslot + 255) / 256), 1, (nw + SURF_WPT - 1) / SURF_WPT);
-    hipLaunchKernelGGL(k_surface, g1, dim3(256), 0, st, k, S.wk, S.geom, S.gflag, nw);
+    hipLaunchKernelGGL(k_surface, g1, dim3(256), 0, st, k, S.wk, S.geom, S.gflag, S.grange, nw);
   }
   {
     Timed t_(c, KID_PROFILE, st);
@@ -3232,6 +3392,34 @@ int slamhip_prof(slamhip_ctx* c, double cs, double* prof_out, double* prof_d_out
   (void)scratch_release(c, c->own, c->stream);
   if (prof_out) std::memcpy(prof_out, hw.prof, sizeof hw.prof);
   if (prof_d_out) *prof_d_out = hw.prof_d;
+  return SLAMHIP_OK;
+}
+
+int slamhip_group_counts(slamhip_ctx* c, int nw, int64_t* out) {
+  if (!c || c->wgroup < 1) return SLAMHIP_ERR_STATE;
+  if (!out || nw < 1 || nw > c->own.wgroup) return fail(c, SLAMHIP_ERR_ARG, "group_counts: bad arguments");
+  if (c->k.mom0decon || !c->fused || c->conv_mode == 1)
+    return fail(c, SLAMHIP_ERR_ARG, "group_counts: fused scaling='uniform' path only");
+  HIP_TRY(c, hipSetDevice(c->device));
+  Scratch& S = c->own;
+  int rc = scratch_acquire(c, S, c->stream);
+  if (rc) return rc;
+  const FitK& k = c->k;
+  // the counters live in the (re-initialised every group) tail of the ticket words
+  unsigned long long* cnt = reinterpret_cast<unsigned long long*>(S.livecount + 16);
+  HIP_TRY(c, hipMemsetAsync(cnt, 0, 8 * sizeof(unsigned long long), c->stream));
+  hipLaunchKernelGGL(k_count_windows, dim3(512), dim3(256), 0, c->stream, S.livelist, S.livecount,
+                     c->fz_sy + 1, c->kpad, cnt);
+  hipLaunchKernelGGL(k_count_flags, dim3(1024), dim3(256), 0, c->stream, S.flags,
+                     (long long)nw * k.nv * c->ftx * c->fty, S.gflag, (long long)nw * (k.nslot >> 6), cnt);
+  hipLaunchKernelGGL(k_count_hits, dim3((unsigned)(k.nslot / 256)), dim3(256), 0, c->stream, k, S.wk,
+                     S.geom, S.gflag, nw, cnt);
+  HIP_TRY(c, hipGetLastError());
+  unsigned long long h[8];
+  hipError_t e = hipMemcpyAsync(h, cnt, sizeof h, hipMemcpyDeviceToHost, c->stream);
+  rc = single_finish(c, e, "group_counts");
+  if (rc) return rc;
+  for (int i = 0; i < 8; ++i) out[i] = (int64_t)h[i];
   return SLAMHIP_OK;
 }
 

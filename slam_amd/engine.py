@@ -250,6 +250,15 @@ class HipLikelihood:
         return {self._lib.slamhip_kernel_name(i).decode(): (float(ms[i]), int(cnt[i]))
                 for i in range(n)}
 
+    def group_counts(self, nw):
+        """Counts of what the last launch group of `nw` walkers touched (see
+        slamhip_group_counts), as a dict."""
+        out = (C.c_int64 * 8)()
+        self._check(self._lib.slamhip_group_counts(self._ctx, int(nw), out), 'group_counts')
+        keys = ('live_windows', 'window_tiles', 'window_rows', 'col_blocks', 'lit_planes',
+                'geom_groups', 'profile_hits', 'profile_wave_hits')
+        return {k: int(out[i]) for i, k in enumerate(keys)}
+
     def set_conv_mode(self, mode):
         self._check(self._lib.slamhip_set_conv_mode(self._ctx, int(mode)),
                     'set_conv_mode')

@@ -33,9 +33,11 @@ def axes(N, NV):
 
 
 def make_fit(config='C3', bpa=0.0, seed=12345, N=None, NV=None, beam_px=None,
-             verbose=False, max_scratch_bytes=0, scaling='uniform'):
+             verbose=False, max_scratch_bytes=0, scaling='uniform', envelope=False):
     """Return a `ChannelFit` with a SYN-v1 cube loaded and `makegrid` done.
-    The data are the same for every `scaling` (truth from the 'uniform' model)."""
+    The data are the same for every `scaling` and `envelope` (truth from the
+    'uniform' disk-only model); `envelope=True` only switches the class flag
+    (:223), which makes every sample beyond Rc emit (the dense-sky workload)."""
     from .channelfit import ChannelFit
     n, nv, bmaj_px, bmin_px = CONFIGS[config] if config in CONFIGS else (N, NV, *beam_px)
     if N is not None:
@@ -59,17 +61,27 @@ def make_fit(config='C3', bpa=0.0, seed=12345, N=None, NV=None, beam_px=None,
         rng = np.random.default_rng(seed)
         data = truth + rng.normal(0.0, SIGMA, truth.shape)
         fit.close()
-        if scaling != 'uniform':
-            fit = ChannelFit(scaling=scaling, progressbar=False)
+        if scaling != 'uniform' or envelope:
+            fit = ChannelFit(scaling=scaling, envelope=envelope, progressbar=False)
         fit.set_cube(x, y, v, data, bmaj_px * dpix, bmin_px * dpix, bpa, SIGMA)
         fit.makegrid(cubefits=None, **kw)
     return fit
 
 
-def walkers(nw, seed=2024):
-    """Natural-unit parameter rows [nw, 13]: (log Mstar, log Rc, h1, h2, pI)
-    uniform in the example's priors (reference example_channelfit.py:22-32),
-    cs = 0.4, everything else 0."""
+WORKLOADS = ('sparse', 'dense_disk', 'envelope')
+
+
+def walkers(nw, seed=2024, workload='sparse'):
+    """Natural-unit parameter rows [nw, 13].
+
+    'sparse' (the headline): (log Mstar, log Rc, h1, h2, pI) uniform in the
+    example's priors (reference example_channelfit.py:22-32), cs = 0.4,
+    everything else 0.
+    'dense_disk': the same with a large, broad-lined disk -- Rc in [250, 300] au,
+    Mstar in [0.5, 1], cs = 1.0 km/s -- which lights most of the sky in most
+    channels.
+    'envelope': the 'sparse' rows with Ienv = 1, for a fit made with
+    `envelope=True` (every sample beyond Rc emits; nothing is culled by radius)."""
     u = np.random.default_rng(seed).random((nw, 5))
     P = np.zeros((nw, 13))
     P[:, 0] = 10**(np.log10(0.1) + u[:, 0] * (np.log10(1.0) - np.log10(0.1)))
@@ -78,6 +90,14 @@ def walkers(nw, seed=2024):
     P[:, 3] = 0.5 * u[:, 2]
     P[:, 4] = 0.5 * u[:, 3]
     P[:, 5] = 3.0 * u[:, 4]
+    if workload == 'dense_disk':
+        P[:, 0] = 0.5 + 0.5 * u[:, 0]
+        P[:, 1] = 250. + 50. * u[:, 1]
+        P[:, 2] = 1.0
+    elif workload == 'envelope':
+        P[:, 7] = 1.0
+    elif workload != 'sparse':
+        raise ValueError(f'workload {workload!r}: expected one of {WORKLOADS}')
     return P
 
 

@@ -1,10 +1,32 @@
-import json, sys
-d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
-r = d['roofline']
-print('evals/s', round(d['value'], 1), 'ms/step', round(d['ms_per_step'], 2),
-      'dominant', r['kernel'], 'frac', round(r['frac'], 4),
-      'pipeline frac', round(r['pipeline']['frac'], 4) if 'pipeline' in r else '-')
-for k, v in r['per_kernel'].items():
-    print(f"  {k:12s} {v['ms_per_launch']:.4f} ms/launch x{v['launches']}  {v['ms_per_eval']*1e3:8.2f} us/eval  share {v['share']:.3f}")
-if 'cpu_baseline' in d:
-    print('cpu', d['cpu_baseline']['value'], d['cpu_baseline']['unit'], 'err', d['cpu_baseline'].get('max_rel_err_vs_gpu'))
+"""Print the lines of one or more bench JSON files (last '{' line of each, or every
+line of a .jsonl) as a table: evals/s, per-kernel us/eval, roofline fractions."""
+import json
+import sys
+
+
+def show(d):
+    r = d['roofline']
+    print(f"{d['config']['workload']}")
+    print(f"  evals/s {d['value']:.1f}  ms/step {d['ms_per_step']:.2f}  bound {r.get('bound')}"
+          f"  frac {r.get('frac')}  hbm {r.get('hbm', {}).get('frac')}  traffic_frac {r.get('traffic_frac')}"
+          f"  dense-bytes x peak {r.get('algorithmic_x_peak')}")
+    for k, v in r['per_kernel'].items():
+        extra = ''
+        if 'hbm_frac' in v:
+            extra += f"  hbm {v['hbm_frac']:.3f}"
+        if 'fp64_frac' in v:
+            extra += f"  fp64 {v['fp64_frac']:.3f}"
+        print(f"    {k:12s} {v['ms_per_launch']:9.4f} ms/launch x{v['launches']:<4d} "
+              f"{v['ms_per_eval'] * 1e3:8.2f} us/eval  share {v['share']:.3f}{extra}")
+    if 'cpu_baseline' in d:
+        c = d['cpu_baseline']
+        print('  cpu', c['value'], c['unit'], 'cores', c['cores'], 'err', c.get('max_rel_err_vs_gpu'),
+              'all_cores', c.get('all_cores', {}).get('value'))
+
+
+for path in sys.argv[1:]:
+    lines = [l for l in open(path) if l.startswith('{')]
+    if not path.endswith('.jsonl'):
+        lines = lines[-1:]
+    for l in lines:
+        show(json.loads(l))

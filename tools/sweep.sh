@@ -1,0 +1,15 @@
+#!/bin/bash
+# Run ON THE GPU BOX (via gpurun): secondary bench lines -- sampler-sized batches and
+# dense-sky workloads -- into gpurun_out/sweep_<tag>.jsonl (one JSON line per run).
+# usage: tools/sweep.sh <tag>
+set -o pipefail
+tag=$1
+out=gpurun_out/sweep_$tag.jsonl
+: > $out
+run() { timeout -k 10 300 python bench.py --cpu-evals 0 --cpu-procs 0 "$@" 2>> gpurun_out/sweep_$tag.err | grep '^{' >> $out || exit 1; }
+for w in 40 80 256 1024; do run --walkers $w --steps 5 --warmup 2; done
+run --workload dense_disk --walkers 256 --steps 2 --warmup 1
+run --workload envelope --walkers 256 --steps 2 --warmup 1
+run --config C2 --walkers 64 --steps 10 --warmup 2
+run --bpa 20 --walkers 1024 --steps 2 --warmup 1
+echo done
