@@ -549,20 +549,25 @@ template <bool FAST>
 __global__ void __launch_bounds__(256)
 k_profile(FitK g, const WalkerK* __restrict__ wk, const double2* __restrict__ geom,
           const unsigned* __restrict__ gflag, double* __restrict__ iunif, unsigned char* __restrict__ flags, int ftx, int fty,
-          unsigned char* __restrict__ winflag, int wnx, int wny, int wsx, int wsy) {
+          unsigned char* __restrict__ winflag, int wnx, int wny, int wsx, int wsy,
+          const uint2* __restrict__ items, const int* __restrict__ nitems) {
   __shared__ double s_prof[PROF_LEN];
   __shared__ unsigned s_mask[4];
-  // XCD-aware block order: blocks b and b+8 share an XCD (and its L2), so the
-  // channel blocks of one pixel tile, which all read the tile's geometry, are
-  // given ids 8 apart: id = ((tile/8 * nchunk + cix) * 8 + tile%8) per walker.
-  const int nchunk = g.nvpad / CH;
-  const int ntile = ftx * fty, tgroups = (ntile + 7) / 8;
-  const int per_walker = tgroups * nchunk * 8;
-  const int wi = blockIdx.x / per_walker;
-  const int lid = blockIdx.x - wi * per_walker;
-  const int cix = (lid >> 3) % nchunk;
-  const int tile = ((lid >> 3) / nchunk) * 8 + (lid & 7);
-  if (tile >= ntile) return;
+  // One workgroup per listed (walker, tile, channel block); the grid is sized for
+  // every triple, workgroups past the end of k_plan's list leave at once.
+  // XCD-aware order: blocks b and b+8 share an XCD (and its L2), and a tile's
+  // channel blocks, which all read the tile's geometry, are neighbours in the
+  // list: XCD x takes the x-th eighth of the list.
+  const int nit = *nitems;
+  const int per_xcd = (nit + 7) >> 3;
+  const int it = (int)(blockIdx.x & 7u) * per_xcd + (int)(blockIdx.x >> 3);
+  if ((int)(blockIdx.x >> 3) >= per_xcd || it >= nit) return;
+  const uint2 item = items[it];                           // block-uniform: kept in SGPRs, so that
+  const unsigned ixw = __builtin_amdgcn_readfirstlane(item.x);   // everything indexed by it is scalar too
+  const int ntile = ftx * fty;
+  const int wi = (int)(ixw / (unsigned)ntile);
+  const int tile = (int)(ixw - (unsigned)wi * (unsigned)ntile);
+  const int cix = (int)__builtin_amdgcn_readfirstlane(item.y);
   const int tby = tile / ftx, tbx = tile - tby * ftx;
   const WalkerK& w = wk[wi];
   const int tid = threadIdx.x;
@@ -607,9 +612,59 @@ k_profile(FitK g, const WalkerK* __restrict__ wk, const double2* __restrict__ ge
     double tks[CH];
 #pragma unroll
     for (int c = 0; c < CH; ++c) tks[c] = FAST ? tkp[c] : 0.0;
+    // one stored {vlos, weight} entry into the block's 16 channels
+    auto lookups = [&](const double vl, const double wt) {
+      const double o = vl + voff;
+      if (fabs(o - cmid) > hwc) return;                   // no channel of this block is lit
+      hit = true;
+      // table index of every channel, fast form (differs from the reference's
+      // iv by < 1e-12); lanes within IDX_GUARD of an integer redo it exactly
+      int idx[CH];
+      bool near = false;
+      if (FAST) {
+        // one fp64 add per channel (see IDX_BIAS): the low word of the sum is
+        // t's fraction, the high word its integer part + IDX_HI0, kept in that
+        // form until the clamp.  The sum is off by at most one unit of 2^-32 and
+        // the fast t by < 1e-11 from the reference's; the bias carries
+        // +IDX_FGUARD, so "near an integer" is fraction < 2*IDX_FGUARD, and the
+        // high word is the reference's index whenever the lane is not near.
+        const double base = fma(-o, R, IDX_BIAS);
+        unsigned lowest = 0xFFFFFFFFu;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+          const double sum = tks[c] + base;
+          lowest = min(lowest, (unsigned)__double2loint(sum));
+          idx[c] = __double2hiint(sum);
+        }
+        near = lowest < 2u * IDX_FGUARD;
+      } else {
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+          const double t = fma(vks[c] - o, rinv, 22.5);
+          near |= fabs(t - rint(t)) < IDX_GUARD;
+          idx[c] = (int)t;                                // saturating; NaN -> 0
+        }
+      }
+      if (near) {
+        // iv = ((v_valid - vlos) - voff) / dv / prof_d + prof_n//2 + 0.5   (:461-462)
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+          double v = (FAST ? vk[c] : vks[c]) - vl;
+          v = v - voff;
+          const int ix = (int)(v / g.dv / w.prof_d + 22.0 + 0.5);
+          acc[c] = fma(s_prof[min(max(ix, 0), PROF_N)], wt, acc[c]);
+        }
+      } else {
+        constexpr int I0 = FAST ? IDX_HI0 : 0;            // FAST: idx holds IDX_HI0 + index
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+          acc[c] = fma(s_prof[min(max(idx[c], I0), I0 + PROF_N) - I0], wt, acc[c]);
+      }
+    };
     // Flags run two ranks ahead of the work, entries one (the word for rank i+2
     // stays in a VGPR until it is needed: moving it to an SGPR at once would
-    // wait for the load).
+    // wait for the load).  (Walking only the stored (rank, surface) pairs with four
+    // loads in flight was tried: 29.8 instead of 28.2 us/eval.)
     unsigned fcur = 0, fnxt = __builtin_amdgcn_readfirstlane(f0v);
     unsigned fnn = f1v;
     double2 q[4], qn[4];
@@ -630,59 +685,10 @@ k_profile(FitK g, const WalkerK* __restrict__ wk, const double2* __restrict__ ge
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         if (!((fcur >> s) & 1u)) continue;                // surface absent, or nothing stored for this wave
-        const double vl = q[s].x, wt = q[s].y;
-        const double o = vl + voff;
-        if (fabs(o - cmid) > hwc) continue;               // no channel of this block is lit
-        hit = true;
-        // table index of every channel, fast form (differs from the reference's
-        // iv by < 1e-12); lanes within IDX_GUARD of an integer redo it exactly
-        int idx[CH];
-        bool near = false;
-        if (FAST) {
-          // one fp64 add per channel (see IDX_BIAS): the low word of the sum is
-          // t's fraction, the high word its integer part + IDX_HI0, kept in that
-          // form until the clamp.  The sum is off by at most one unit of 2^-32 and
-          // the fast t by < 1e-11 from the reference's; the bias carries
-          // +IDX_FGUARD, so "near an integer" is fraction < 2*IDX_FGUARD, and the
-          // high word is the reference's index whenever the lane is not near.
-          const double base = fma(-o, R, IDX_BIAS);
-          unsigned lowest = 0xFFFFFFFFu;
-#pragma unroll
-          for (int c = 0; c < CH; ++c) {
-            const double sum = tks[c] + base;
-            lowest = min(lowest, (unsigned)__double2loint(sum));
-            idx[c] = __double2hiint(sum);
-          }
-          near = lowest < 2u * IDX_FGUARD;
-        } else {
-#pragma unroll
-          for (int c = 0; c < CH; ++c) {
-            const double t = fma(vks[c] - o, rinv, 22.5);
-            near |= fabs(t - rint(t)) < IDX_GUARD;
-            idx[c] = (int)t;                              // saturating; NaN -> 0
-          }
-        }
-        if (near) {
-          // iv = ((v_valid - vlos) - voff) / dv / prof_d + prof_n//2 + 0.5   (:461-462)
-#pragma unroll
-          for (int c = 0; c < CH; ++c) {
-            double v = (FAST ? vk[c] : vks[c]) - vl;
-            v = v - voff;
-            const int ix = (int)(v / g.dv / w.prof_d + 22.0 + 0.5);
-            acc[c] = fma(s_prof[min(max(ix, 0), PROF_N)], wt, acc[c]);
-          }
-        } else {
-          constexpr int I0 = FAST ? IDX_HI0 : 0;          // FAST: idx holds IDX_HI0 + index
-#pragma unroll
-          for (int c = 0; c < CH; ++c)
-            acc[c] = fma(s_prof[min(max(idx[c], I0), I0 + PROF_N) - I0], wt, acc[c]);
-        }
+        lookups(q[s].x, q[s].y);
       }
     }
-    if (!__syncthreads_or(hit)) {                         // empty sky in this channel block
-      if (tid < CH && kf < g.nv) fl[(long long)kf * ftile] = 0;
-      return;
-    }
+    if (!__syncthreads_or(hit)) return;                   // empty sky after all: the flags stay 0
     unsigned m = 0;
 #pragma unroll
     for (int c = 0; c < CH; ++c) m |= (unsigned)(acc[c] != 0.0) << c;
@@ -691,8 +697,8 @@ k_profile(FitK g, const WalkerK* __restrict__ wk, const double2* __restrict__ ge
     __syncthreads();
     m = s_mask[0] | s_mask[1] | s_mask[2] | s_mask[3];
     if (tid < CH && kf < g.nv) {
-      fl[(long long)kf * ftile] = (m >> tid) & 1u;
-      if ((m >> tid) & 1u) {                              // mark the conv windows this tile feeds
+      if ((m >> tid) & 1u) {                              // lit: occupancy byte, and the conv windows this tile feeds
+        fl[(long long)kf * ftile] = 1;
         const int px0 = tbx * PT_X, py0 = tby * PT_Y;
         const int wbx0 = max(0, (px0 - (CONV_TX - 1) - g.ngauss + wsx - 1) / wsx);
         const int wbx1 = min(wnx - 1, (px0 + PT_X - 1 + g.ngauss) / wsx);
@@ -2551,16 +2557,22 @@ int run_model(slamhip_ctx* c, Scratch& S, const double* d_params, int nw, hipStr
   }
   {
     Timed t_(c, KID_PROFILE, st);
-    const int tgroups = (c->ftx * c->fty + 7) / 8;
-    dim3 g2((unsigned)tgroups * 8u * (unsigned)(k.nvpad / CH) * (unsigned)nw, 1, 1);
+    const int ntile = c->ftx * c->fty;
+    // occupancy bytes start at zero; k_profile raises those of the blocks it lights
+    HIP_TRY(c, hipMemsetAsync(S.flags, 0, (size_t)nw * k.nv * ntile, st));
+    int* nitems = S.livecount + 2;               // zeroed by k_prep with the other counters
+    hipLaunchKernelGGL(k_plan, dim3((unsigned)((nw * ntile + 255) / 256)), dim3(256), 0, st, k, S.wk,
+                       S.grange, nw, ntile, S.items, nitems);
+    // room for every triple (rounded up to whole groups of 8 for the XCD mapping)
+    dim3 g2((unsigned)(((size_t)nw * ntile * (k.nvpad / CH) + 7) / 8 * 8), 1, 1);
     if (k.fast_idx)
       hipLaunchKernelGGL(k_profile<true>, g2, dim3(256), 0, st, k, S.wk, S.geom, S.gflag,
                          S.iunif, S.flags, c->ftx, c->fty, S.winflag, (int)c->fz_grid.x, (int)c->fz_grid.y,
-                         c->fz_sx, c->fz_sy);
+                         c->fz_sx, c->fz_sy, S.items, nitems);
     else
       hipLaunchKernelGGL(k_profile<false>, g2, dim3(256), 0, st, k, S.wk, S.geom, S.gflag,
                          S.iunif, S.flags, c->ftx, c->fty, S.winflag, (int)c->fz_grid.x, (int)c->fz_grid.y,
-                         c->fz_sx, c->fz_sy);
+                         c->fz_sx, c->fz_sy, S.items, nitems);
   }
   HIP_TRY(c, hipGetLastError());
   return SLAMHIP_OK;
