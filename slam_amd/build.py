@@ -16,7 +16,9 @@ TARGETS = [
 SRC, _, OUT = TARGETS[0]
 
 
-def build(force=False, verbose=True):
+def build(force=False, verbose=True, stamps=False):
+    """`stamps`: diagnostic build of libslamhip.so with in-kernel phase stamps
+    (k_conv_chi2; read by slamhip_group_counts on stderr).  Never the product."""
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     outs = []
     for src, hdr, out in TARGETS:
@@ -26,6 +28,8 @@ def build(force=False, verbose=True):
             continue
         cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared',
                '-ffp-contract=off', '-I', os.path.join(ROOT, 'include'), src, '-o', out]
+        if stamps and src.endswith('slamhip.hip'):
+            cmd.insert(1, '-DSLAMHIP_PHASE_STAMPS')
         if verbose:
             print(' '.join(cmd), flush=True)
         subprocess.check_call(cmd)
@@ -33,4 +37,4 @@ def build(force=False, verbose=True):
 
 
 if __name__ == '__main__':
-    build(force='--force' in sys.argv)
+    build(force='--force' in sys.argv or '--stamps' in sys.argv, stamps='--stamps' in sys.argv)

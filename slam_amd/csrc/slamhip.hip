@@ -57,7 +57,7 @@ constexpr double IDX_BIAS = (22.5 + IDX_OFF) * IDX_SCALE + IDX_FGUARD + 45035996
 constexpr int IDX_HI0 = 0x43300000 + IDX_OFF;         // high word of the sum for floor(t) = 0
 constexpr int MAX_RANK = 24;                 // beam outer-product terms the fused kernel accepts
 constexpr unsigned LEAF_PAD = 0xffffffffu;    // slot without a sample
-constexpr int DIRECT_PITCH = (CONV_TX + 32 - 1) | 1;   // fused direct taps, kpad <= 32: LDS tile pitch
+constexpr int DIRECT_PITCH = (CONV_TX + 32) | 1;       // fused direct taps, kpad <= 32: LDS tile pitch (room for the staging's column shift)
 constexpr int DIRECT_MIN_RANK = 6;           // beams needing this many terms or more get direct taps in the fused kernel
 constexpr int PREP_TILES = 1024;             // conv windows per axis pair k_prep can index (ntx + nty)
 constexpr int FLAG_MAX = 512;                // occupancy bytes one conv window may span
@@ -1022,6 +1022,13 @@ k_compact(FitK g, const unsigned char* __restrict__ winflag, int total,
 constexpr int CV_NT = 512;                   // threads per workgroup
 constexpr int CV_NW = CV_NT / 64;            // waves
 
+// Workgroup barrier for LDS traffic only: waits for this wave's LDS operations, not
+// for its global loads (__syncthreads() also drains vmcnt, which would expose the
+// latency of every load that is meant to fly across the barrier).
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 template <int TY, int MAXR, bool DIRECT, int PITCH = 0>   // PITCH: LDS tile pitch fixed at compile time (0: from kpad)
 __global__ void __launch_bounds__(CV_NT, 4)
 k_conv_chi2(FitK g, const double* __restrict__ iunif,
@@ -1044,7 +1051,7 @@ k_conv_chi2(FitK g, const double* __restrict__ iunif,
   const int K = g.kbeam, ng = g.ngauss, n = g.nneed;
   const int rows = TY + kpad - 1, cols = TX + kpad - 1;
   // a compile-time pitch turns the direct taps' row offsets into immediates
-  const int P = PITCH ? PITCH : (cols | 1);
+  const int P = PITCH ? PITCH : ((cols + 1) | 1);           // odd, with room for the column shift of the staging
   const int vrows = TY + K - 1, vcols = TX + K - 1;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave index, kept scalar
@@ -1053,7 +1060,7 @@ k_conv_chi2(FitK g, const double* __restrict__ iunif,
   // the row-pass output overlays the input tile; with several the tile must
   // survive, so the intermediate gets LDS of its own.
   // taps sit after the tile; DIRECT also parks two TY x PC half sums in the tile's place
-  double* wxl = lds + (DIRECT ? max(rows * P, 2 * TY * PC) : rows * P);   // [nrank][kpad] flipped taps, zero padded
+  double* wxl = lds + (DIRECT ? max(rows * P + 1, 2 * TY * PC) : rows * P + 1);   // [nrank][kpad] flipped taps, zero padded
   double* wyl = wxl + nrank * kpad;
   double* tmp = nrank == 1 ? lds : wyl + nrank * kpad;      // [rows][P2]
   for (int e = tid; e < nrank * kpad; e += CV_NT) { wxl[e] = g.gx_pad[e]; wyl[e] = g.gy_pad[e]; }
@@ -1074,6 +1081,17 @@ k_conv_chi2(FitK g, const double* __restrict__ iunif,
   int nxt = __builtin_amdgcn_readfirstlane(s_ticket);     // block-uniform, kept scalar
   // every wave reaches the loop exit: tickets only grow, and a workgroup stops
   // drawing once it holds one past the end of the list
+  // Diagnostic build only (-DSLAMHIP_PHASE_STAMPS, `python -m slam_amd.build --stamps`):
+  // cycles of wave 0 per phase of the window loop, summed into the spare counter
+  // words behind the ticket; the product build has no stamp.
+#ifdef SLAMHIP_PHASE_STAMPS
+  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev;
+#define STAMP_NOW(t_) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define STAMP(p_) do { unsigned long long t_; STAMP_NOW(t_); tacc[p_] += t_ - tprev; tprev = t_; } while (0)
+  STAMP_NOW(tprev);
+#else
+#define STAMP(p_) do { } while (0)
+#endif
   int par = 0;
   for (int it = blockIdx.x; it < nlive; par ^= 1) {
     // next window's descriptor: in flight during this window, parked in LDS at its end
@@ -1083,9 +1101,16 @@ k_conv_chi2(FitK g, const double* __restrict__ iunif,
     int fut = nlive;
     if (tid == 0 && nxt < nlive) fut = (int)gridDim.x + atomicAdd(queue, 1);
     const WinDesc* cur = reinterpret_cast<const WinDesc*>(&s_desc[par][0]);   // in LDS
-    const int e = __builtin_amdgcn_readfirstlane(cur->e);   // descriptor fields are block-uniform: keep them scalar
-    const int z = __builtin_amdgcn_readfirstlane(cur->z);
-    const int tb = __builtin_amdgcn_readfirstlane(cur->tb);
+    // The descriptor's fields are block-uniform and live in SGPRs.  ONE LDS round
+    // trip fetches them all: lane l reads dword l of the head (16 dwords: ids and
+    // ranges, then the row masks) and, in the same wait, lane l's tile id; the
+    // values are then picked lane by lane (v_readlane needs no wait).
+    const unsigned hd = s_desc[par][lane & 15];
+    const unsigned idv = reinterpret_cast<const unsigned short*>(cur->ids)[lane < WIN_IDS ? lane : 0];
+    auto head = [&](int i) { return (int)__builtin_amdgcn_readlane(hd, i); };
+    const int e = head(0);
+    const int z = head(6);
+    const int tb = head(7);
     const int tby = tb >> 16, tbx = tb & 0xffff;
     const int wi = z / g.nv, k = z - wi * g.nv;
     const double* src = iunif + (long long)z * n * n;
@@ -1093,50 +1118,62 @@ k_conv_chi2(FitK g, const double* __restrict__ iunif,
     const int wx0 = x0 - ng, wy0 = y0 - ng;                 // window origin (image coords)
     const int ftx0 = max(wx0, 0) / PT_X, fty0 = max(wy0, 0) / PT_Y;
     const int fnx = min(wx0 + vcols - 1, n - 1) / PT_X - ftx0 + 1;
-    const int nocc = __builtin_amdgcn_readfirstlane(cur->nocc);
+    const int nocc = head(5);
 
-    // -- 0. issue the loads of the occupied input tiles now (NSB per wave in registers)
-    double sv[NSB][4];
-    int srr[NSB], scc[NSB];
+    // -- 0. issue the loads of the occupied input tiles now (NSB per wave in registers).
+    // A lane takes one row of a 32x8 tile and two 16-byte column pairs of it (columns
+    // pcol, pcol+1 and pcol+16, pcol+17).  Image columns are paired from an even index
+    // and rows have an even pitch, so a pair is one aligned 16-byte load; the window's
+    // column 0 sits at LDS column `woff` = wx0 & 1, which keeps every pair whole inside
+    // the tile (a pair may spill one column into the pad on either side: column -1 is
+    // never read, column vcols only against zero taps).
+    const int woff = wx0 & 1;
+    double* tile = lds + woff;
+    const int prow = lane >> 3, pcol = (lane & 7) * 2;
+    // position of tile (fyy, fxx) for this lane: LDS offset of its first pair, or -1;
+    // bit 0 / 1 of `ok`: first / second pair inside the window
+    auto tile_pos = [&](int fyy, int fxx, int& gofs, int& ok) {
+      const int gy = (fty0 + fyy) * PT_Y + prow;
+      const int gx = (ftx0 + fxx) * PT_X + pcol;
+      const int rr = gy - wy0, cc = gx - wx0;
+      const bool rowok = gy < n && rr >= 0 && rr < vrows;
+      ok = (rowok && gx < n && cc >= -woff && cc < vcols ? 1 : 0) |
+           (rowok && gx + 16 < n && cc + 16 >= -woff && cc + 16 < vcols ? 2 : 0);
+      gofs = gy * n + gx;
+      return rr * P + cc;
+    };
+    double2 sa[NSB], sb[NSB];
+    int sofs[NSB], sok[NSB];
 #pragma unroll
     for (int u = 0; u < NSB; ++u) {
       const int bq = wv + CV_NW * u;
-      srr[u] = -1;
-      scc[u] = 0;
-      sv[u][0] = sv[u][1] = sv[u][2] = sv[u][3] = 0.0;
+      sok[u] = 0;
+      sofs[u] = 0;
+      sa[u] = sb[u] = make_double2(0.0, 0.0);
       if (bq < nocc && bq < WIN_IDS) {
-        const int q = __builtin_amdgcn_readfirstlane((int)cur->ids[bq]);   // wave-uniform
-        const int fyy = q >> 8, fxx = q & 255;
-        const int gy = (fty0 + fyy) * PT_Y + (lane >> 3);
-        const int gx0 = (ftx0 + fxx) * PT_X + (lane & 7) * 4;
-        const int rr = gy - wy0;
-        const bool rowok = gy < n && rr >= 0 && rr < vrows;
-        srr[u] = rowok ? rr : -1;
-        scc[u] = gx0 - wx0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int gx = gx0 + j, cc = gx - wx0;
-          sv[u][j] = (rowok && gx < n && cc >= 0 && cc < vcols) ? src[(long long)gy * n + gx] : 0.0;
-        }
+        const int q = (int)__builtin_amdgcn_readlane(idv, bq);             // wave-uniform
+        int gofs;
+        sofs[u] = tile_pos(q >> 8, q & 255, gofs, sok[u]);
+        const double2* rp = reinterpret_cast<const double2*>(src + gofs);
+        if (sok[u] & 1) sa[u] = rp[0];
+        if (sok[u] & 2) sb[u] = rp[8];
       }
     }
     const double* dat = g.data + (long long)k * g.ny * g.nx;
-    const int ixa = __builtin_amdgcn_readfirstlane(cur->ixa), ixb = __builtin_amdgcn_readfirstlane(cur->ixb);
-    const int jya = __builtin_amdgcn_readfirstlane(cur->jya), jyb = __builtin_amdgcn_readfirstlane(cur->jyb);
+    const int ixa = head(1), ixb = head(2);
+    const int jya = head(3), jyb = head(4);
     const int ix = ixa + lane;
     int i1 = -1;
     double t1 = 0.0;
     double dv[NRQ], t0q[NRQ];
     int i0q[NRQ];
 
+    STAMP(0);
     // -- 1. rows that hold emission; zero them in the LDS tile
-    auto uniform64 = [](unsigned long long v) {             // block-uniform value into SGPRs
-      const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
-      const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-      return ((unsigned long long)hi << 32) | lo;
+    auto head64 = [&](int i) {
+      return ((unsigned long long)(unsigned)head(i + 1) << 32) | (unsigned)head(i);
     };
-    const unsigned long long m0 = uniform64(cur->rowmask[0]), m1 = uniform64(cur->rowmask[1]),
-                             m2 = uniform64(cur->rowmask[2]), m3 = uniform64(cur->rowmask[3]);
+    const unsigned long long m0 = head64(8), m1 = head64(10), m2 = head64(12), m3 = head64(14);
     const int nlr = __popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3);
     if (tid < rows) {
       const unsigned long long mw = tid < 64 ? m0 : tid < 128 ? m1 : tid < 192 ? m2 : m3;
@@ -1159,18 +1196,15 @@ k_conv_chi2(FitK g, const double* __restrict__ iunif,
         }
       }
     }
-    __syncthreads();
+    lds_barrier();
+    STAMP(1);
 
     // -- 2. staged tiles into LDS
 #pragma unroll
-    for (int u = 0; u < NSB; ++u)
-      if (srr[u] >= 0) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int cc = scc[u] + j;
-          if (cc >= 0 && cc < vcols) lds[srr[u] * P + cc] = sv[u][j];
-        }
-      }
+    for (int u = 0; u < NSB; ++u) {
+      if (sok[u] & 1) { tile[sofs[u]] = sa[u].x; tile[sofs[u] + 1] = sa[u].y; }
+      if (sok[u] & 2) { tile[sofs[u] + 16] = sb[u].x; tile[sofs[u] + 17] = sb[u].y; }
+    }
     if (nocc > NSB * CV_NW) {
       // crowded window: the remaining occupied tiles, loaded and stored directly
       const unsigned long long* occ = cur->occ;
@@ -1182,21 +1216,17 @@ k_conv_chi2(FitK g, const double* __restrict__ iunif,
           m &= m - 1;
           const int b = seen++;
           if (b < NSB * CV_NW || (b & (CV_NW - 1)) != wv) continue;
-          const int fyy = q / fnx, fxx = q - fyy * fnx;
-          const int gy = (fty0 + fyy) * PT_Y + (lane >> 3);
-          const int gx0 = (ftx0 + fxx) * PT_X + (lane & 7) * 4;
-          const int rr = gy - wy0;
-          if (gy < n && rr >= 0 && rr < vrows) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const int gx = gx0 + j, cc = gx - wx0;
-              if (gx < n && cc >= 0 && cc < vcols) lds[rr * P + cc] = src[(long long)gy * n + gx];
-            }
-          }
+          const int fyy = q / fnx;
+          int gofs, ok;
+          const int o = tile_pos(fyy, q - fyy * fnx, gofs, ok);
+          const double2* rp = reinterpret_cast<const double2*>(src + gofs);
+          if (ok & 1) { const double2 v = rp[0]; tile[o] = v.x; tile[o + 1] = v.y; }
+          if (ok & 2) { const double2 v = rp[8]; tile[o + 16] = v.x; tile[o + 17] = v.y; }
         }
       }
     }
-    __syncthreads();
+    lds_barrier();
+    STAMP(2);
 
     // -- 3+4. per beam term: row pass over the rows with emission
     //         tmp[row][x] = sum_u gxf[u] tile[row][x+u]   (wave <-> R output columns,
@@ -1219,7 +1249,7 @@ k_conv_chi2(FitK g, const double* __restrict__ iunif,
       // RB*R multiply-adds); tap blocks over rows without emission are skipped
       for (int b = tapset; b < K; b += 2) {
         const double* __restrict__ wb = gbt + b * kpad;     // block-uniform address: scalar loads
-        const double* col = lds + (rb * RB) * P + lane + b;
+        const double* col = tile + (rb * RB) * P + lane + b;
         for (int u0 = 0; u0 < kpad; u0 += R) {
           const int ra = rb * RB + u0;
           unsigned long long bits = 0ull;
@@ -1264,7 +1294,7 @@ k_conv_chi2(FitK g, const double* __restrict__ iunif,
         for (int r = 0; r < R; ++r) res[q][r] = 0.0;
         if (q * 64 < nlr && ridx < nlr) {
           const int rr = s_rowlist[ridx];
-          const double* row = lds + rr * P + wv * R;
+          const double* row = tile + rr * P + wv * R;
           double win[R];
 #pragma unroll
           for (int r = 0; r < R - 1; ++r) win[r] = row[r];
@@ -1280,7 +1310,8 @@ k_conv_chi2(FitK g, const double* __restrict__ iunif,
           }
         }
       }
-      __syncthreads();                  // tile reads (overlay) / previous column pass done
+      STAMP(3);
+      lds_barrier();                  // tile reads (overlay) / previous column pass done
       // rows without emission convolve to zero; the others come from registers
 #pragma unroll
       for (int q = 0; q < MAXR; ++q) {
@@ -1302,7 +1333,8 @@ k_conv_chi2(FitK g, const double* __restrict__ iunif,
           for (int r = 0; r < R; ++r) tmp[rr * P2 + wv * R + r] = res[q][r];
         }
       }
-      __syncthreads();
+      lds_barrier();
+      STAMP(4);
 
       if (wv < TY / R) {
         const double* col = tmp + (wv * R) * P2 + lane;
@@ -1329,6 +1361,7 @@ k_conv_chi2(FitK g, const double* __restrict__ iunif,
         }
       }
     }
+    STAMP(5);
     // what the regrid needs from HBM, requested only now: the passes above want the registers
     if (ix < ixb) {
       i1 = cellx[(long long)wi * g.nx + ix] - x0;
@@ -1343,14 +1376,14 @@ k_conv_chi2(FitK g, const double* __restrict__ iunif,
       dv[q] = (ix < ixb && rowin) ? dat[(long long)jy * g.nx + ix] : 0.0;
     }
     const bool xown = i1 >= 0 && i1 < TX - 1;               // else owned by another window
-    __syncthreads();                                        // column pass done reading LDS
+    lds_barrier();                                        // column pass done reading LDS
     if (DIRECT) {
       double* half = lds + TY * PC;                         // the odd tap columns' sums
       if (tapset == 1) {
 #pragma unroll
         for (int r = 0; r < RB; ++r) half[(rb * RB + r) * PC + lane] = dacc[r];
       }
-      __syncthreads();
+      lds_barrier();
       if (tapset == 0) {
 #pragma unroll
         for (int r = 0; r < RB; ++r)
@@ -1360,8 +1393,9 @@ k_conv_chi2(FitK g, const double* __restrict__ iunif,
 #pragma unroll
       for (int r = 0; r < R; ++r) lds[(wv * R + r) * PC + lane] = acc[r];
     }
-    __syncthreads();
+    lds_barrier();
 
+    STAMP(6);
     // -- 5. regrid + chi-square sums from the LDS tile
     double gf = 0.0, ff = 0.0;
 #pragma unroll
@@ -1401,7 +1435,7 @@ k_conv_chi2(FitK g, const double* __restrict__ iunif,
     if (lane == 0) { sg[wv] = gf; sf[wv] = ff; }
     if (tid < DW) s_desc[par ^ 1][tid] = nextw;
     if (tid == 0) s_ticket = fut;
-    __syncthreads();
+    lds_barrier();
     if (tid == 0) {
       double a = 0.0, b2 = 0.0;
 #pragma unroll
@@ -1410,10 +1444,18 @@ k_conv_chi2(FitK g, const double* __restrict__ iunif,
       partial[3 * (long long)e + 1] = b2;
       partial[3 * (long long)e + 2] = 1.0;                  // window was convolved
     }
+    STAMP(7);
     it = nxt;
     nxt = __builtin_amdgcn_readfirstlane(s_ticket);
     // the next window's first barrier orders its LDS writes after these reads
   }
+#ifdef SLAMHIP_PHASE_STAMPS
+  if (tid == 0) {
+    unsigned long long* dbg = reinterpret_cast<unsigned long long*>(count + 32);
+    for (int p_ = 0; p_ < 8; ++p_) atomicAdd(&dbg[p_], tacc[p_]);
+  }
+#endif
+#undef STAMP
 }
 
 // k_conv_2d: general (rotated) beam, direct K x K taps on an LDS tile.
@@ -2489,6 +2531,13 @@ size_t sep_lds_bytes(int TY, int kpad) {
   return (size_t)rows * std::max(P, CONV_TX + 1) * sizeof(double);
 }
 
+// LDS tile of the fused kernel: pitch cols + 2 (odd; room for the staging's column
+// shift and a pad column) and one leading element.
+size_t fz_tile_bytes(int TY, int kpad) {
+  const size_t rows = TY + kpad - 1, P = ((size_t)CONV_TX + kpad) | 1;
+  return (rows * P + 2) * sizeof(double);
+}
+
 int run_conv(slamhip_ctx* c, const double* in, double* out, int planes,
              hipStream_t st) {
   const int n = c->k.nneed;
@@ -2879,11 +2928,11 @@ int slamhip_create(const slamhip_desc* d, slamhip_ctx** out) {
     }
   }
   c->sep_variant = -1;
-  if (sep_lds_bytes(64, c->kpad) <= 80 * 1024 && (64 + c->kpad - 1) * (CONV_TX / CONV_R) <= 3 * 256) {
+  if (fz_tile_bytes(64, c->kpad) <= 78 * 1024 && (64 + c->kpad - 1) * (CONV_TX / CONV_R) <= 3 * 256) {
     c->sep_variant = 0; c->sep_lds = sep_lds_bytes(64, c->kpad);
-  } else if (sep_lds_bytes(64, c->kpad) + 2 * c->kpad * sizeof(double) <= 156 * 1024 && (64 + c->kpad - 1) * (CONV_TX / CONV_R) <= 5 * 256) {
+  } else if (fz_tile_bytes(64, c->kpad) + 2 * c->kpad * sizeof(double) <= 156 * 1024 && (64 + c->kpad - 1) * (CONV_TX / CONV_R) <= 5 * 256) {
     c->sep_variant = 1; c->sep_lds = sep_lds_bytes(64, c->kpad);
-  } else if (sep_lds_bytes(32, c->kpad) + 2 * c->kpad * sizeof(double) <= 156 * 1024 && (32 + c->kpad - 1) * (CONV_TX / CONV_R) <= 4 * 256) {
+  } else if (fz_tile_bytes(32, c->kpad) + 2 * c->kpad * sizeof(double) <= 156 * 1024 && (32 + c->kpad - 1) * (CONV_TX / CONV_R) <= 4 * 256) {
     c->sep_variant = 2; c->sep_lds = sep_lds_bytes(32, c->kpad);
   }
   c->c2d_lds = (size_t)(C2_TY + K - 1) * ((C2_TX + K - 1) | 1) * sizeof(double);
@@ -2893,7 +2942,8 @@ int slamhip_create(const slamhip_desc* d, slamhip_ctx** out) {
                                          : (const void*)k_conv_sep<32, 4>;
     HIP_TRY(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->sep_lds));
   }
-  c->fz_lds = c->sep_lds + 2 * (size_t)std::max(c->nrank, 1) * c->kpad * sizeof(double);
+  const size_t fz_tile = c->sep_variant < 0 ? 0 : fz_tile_bytes(c->sep_variant == 2 ? 32 : 64, c->kpad);
+  c->fz_lds = fz_tile + 2 * (size_t)std::max(c->nrank, 1) * c->kpad * sizeof(double);
   if (c->nrank > 1 && c->sep_variant >= 0) {
     // several beam terms: the row-pass intermediate cannot overlay the tile
     const int ty = c->sep_variant == 2 ? 32 : 64;
@@ -2908,7 +2958,7 @@ int slamhip_create(const slamhip_desc* d, slamhip_ctx** out) {
     const size_t ty = c->sep_variant == 2 ? 32 : 64;
     // the common case (64-row windows, K <= 32) runs with the tile pitch fixed at DIRECT_PITCH
     c->direct_fixed = c->sep_variant == 0 && c->kpad <= 32;
-    const size_t tile = c->direct_fixed ? (ty + c->kpad - 1) * DIRECT_PITCH * sizeof(double) : c->sep_lds;
+    const size_t tile = c->direct_fixed ? ((ty + c->kpad - 1) * DIRECT_PITCH + 2) * sizeof(double) : fz_tile;
     c->fz_lds_direct = std::max(tile, 2 * ty * (CONV_TX + 1) * sizeof(double));
   }
   const bool direct_ok = c->sep_variant >= 0 && c->fz_lds_direct <= 156 * 1024;   // taps + tile fit the LDS
@@ -3432,6 +3482,13 @@ int slamhip_group_counts(slamhip_ctx* c, int nw, int64_t* out) {
   rc = single_finish(c, e, "group_counts");
   if (rc) return rc;
   for (int i = 0; i < 8; ++i) out[i] = (int64_t)h[i];
+#ifdef SLAMHIP_PHASE_STAMPS
+  {
+    unsigned long long h2[8];
+    (void)hipMemcpy(h2, S.livecount + 32, sizeof h2, hipMemcpyDeviceToHost);
+    for (int i = 0; i < 8; ++i) fprintf(stderr, "stamp %d %llu\n", i, h2[i]);
+  }
+#endif
   return SLAMHIP_OK;
 }
 
