@@ -75,6 +75,8 @@ struct FitK {
   double ssq_data;      // sum(data_valid^2), fixed per fit
   int data_has_nan;
   int fast_idx;         // k_profile may use the fixed-point table index
+  int kpad;             // beam taps padded to a multiple of CONV_R
+  int fold;             // the fused kernel may fold the regrid into the beam taps (one-term beam)
   double* tk;           // per-group scratch [walker][nvpad]: v_k * rinv * 2^32 (k_prep -> k_profile)
   const double* Xnest0;
   const double* Ynest0;
@@ -155,7 +157,9 @@ __global__ void k_prep(FitK g, const double* __restrict__ params, int nw,
                        double* __restrict__ fracx, int* __restrict__ celly,
                        double* __restrict__ fracy, int* __restrict__ tile_ix,
                        int* __restrict__ tile_jy, int ntx, int nty, int sx, int sy,
-                       unsigned char* __restrict__ winflag, int winbytes, int* __restrict__ livecount) {
+                       unsigned char* __restrict__ winflag, int winbytes, int* __restrict__ livecount,
+                       int* __restrict__ foldflag, double* __restrict__ gxw, double* __restrict__ gyw,
+                       int* __restrict__ pcx, int* __restrict__ pcy) {
   const int w = blockIdx.x;
   if (w >= nw) return;
   if (winflag) {
@@ -198,6 +202,66 @@ __global__ void k_prep(FitK g, const double* __restrict__ params, int nw,
     int* o2 = isx ? &tile_ix[((long long)w * ntx + tt) * 2] : &tile_jy[((long long)w * nty + tt) * 2];
     o2[0] = s_hi[tl] == 0 ? 0 : s_lo[tl];
     o2[1] = s_hi[tl];
+  }
+  // Folding the regrid into the beam (k_conv_chi2): when, on an axis, the observed
+  // pixels inside the model grid step through consecutive cells with one and the
+  // same fractional position t, the bilinear regrid (:475-483) is itself a two-tap
+  // convolution [1-t, t], and beam-then-regrid equals ONE pass with the K+1 taps
+  // (1-t) g[u] + t g[u-1] whose outputs land on the observed pixels directly.
+  // Checked per walker and axis (the offsets move t); otherwise the general path.
+  if (foldflag) {
+    __shared__ int s_first[2], s_ok;
+    if (t == 0) { s_first[0] = s_first[1] = 0x7fffffff; s_ok = g.fold; }
+    int* pc0 = pcx + (long long)w * g.nneed;
+    int* pc1 = pcy + (long long)w * g.nneed;
+    for (int c = t; c < g.nneed; c += blockDim.x) { pc0[c] = -1; pc1[c] = -1; }
+    __syncthreads();
+    for (int i = t; i < g.nx + g.ny; i += blockDim.x) {
+      const bool isx = i < g.nx;
+      const int ii = isx ? i : i - g.nx;
+      const int cell = isx ? cellx[(long long)w * g.nx + ii] : celly[(long long)w * g.ny + ii];
+      if (cell >= 0) atomicMin(&s_first[isx ? 0 : 1], ii);
+      if (cell == -2) s_ok = 0;                            // NaN query point
+    }
+    __syncthreads();
+    bool ok = true;
+    double tf[2] = {0.0, 0.0};
+    for (int ax = 0; ax < 2; ++ax) {
+      const int nobs = ax == 0 ? g.nx : g.ny;
+      const int* cl = ax == 0 ? cellx + (long long)w * g.nx : celly + (long long)w * g.ny;
+      const double* fr = ax == 0 ? fracx + (long long)w * g.nx : fracy + (long long)w * g.ny;
+      const int i0 = s_first[ax];
+      if (i0 >= nobs) continue;                            // no pixel inside the grid: nothing to regrid
+      const int c0 = cl[i0];
+      const double t0 = fr[i0];
+      tf[ax] = t0;
+      const int step = (i0 + 1 < nobs && cl[i0 + 1] >= 0) ? cl[i0 + 1] - c0 : 1;
+      if (step != 1 && step != -1) ok = false;
+      for (int i = t; i < nobs; i += blockDim.x) {
+        const int c = cl[i];
+        if (c < 0) continue;
+        if (c != c0 + step * (i - i0) || !(fabs(fr[i] - t0) <= 1e-12)) ok = false;
+      }
+    }
+    if (!ok) s_ok = 0;
+    __syncthreads();
+    const bool fold = s_ok != 0;
+    if (t == 0) foldflag[w] = fold ? 1 : 0;
+    if (fold) {
+      for (int i = t; i < g.nx + g.ny; i += blockDim.x) {  // cell -> the observed pixel inside it
+        const bool isx = i < g.nx;
+        const int ii = isx ? i : i - g.nx;
+        const int cell = isx ? cellx[(long long)w * g.nx + ii] : celly[(long long)w * g.ny + ii];
+        if (cell >= 0) (isx ? pc0 : pc1)[cell] = ii;
+      }
+      for (int u = t; u < 2 * g.kpad; u += blockDim.x) {
+        const bool isx = u < g.kpad;
+        const int v = isx ? u : u - g.kpad;
+        const double* gp = isx ? g.gx_pad : g.gy_pad;
+        const double tt = tf[isx ? 0 : 1];
+        (isx ? gxw : gyw)[(long long)w * g.kpad + v] = (1.0 - tt) * gp[v] + (v > 0 ? tt * gp[v - 1] : 0.0);
+      }
+    }
   }
   const double cs = p[2];
   // update_prof (:412-427)
@@ -1037,7 +1101,9 @@ k_conv_chi2(FitK g, const double* __restrict__ iunif,
             const WinDesc* __restrict__ list, int* __restrict__ count, int wnx, int wny,
             double* __restrict__ partial, int kpad, int nrank,
             const double* __restrict__ gxp, const double* __restrict__ gyp,
-            const double* __restrict__ gbt) {
+            const double* __restrict__ gbt,
+            const int* __restrict__ foldflag, const double* __restrict__ gxw, const double* __restrict__ gyw,
+            const int* __restrict__ pcx, const int* __restrict__ pcy) {
   // DIRECT (nrank == 0): the beam is not worth factorising (a rotated Gaussian
   // needs ~14 terms): direct K x K taps on the staged tile instead of row +
   // column passes
@@ -1119,6 +1185,12 @@ k_conv_chi2(FitK g, const double* __restrict__ iunif,
     const int ftx0 = max(wx0, 0) / PT_X, fty0 = max(wy0, 0) / PT_Y;
     const int fnx = min(wx0 + vcols - 1, n - 1) / PT_X - ftx0 + 1;
     const int nocc = head(5);
+    // Walkers whose regrid folds into the beam (k_prep): the passes below run with the
+    // walker's K+1 taps, their outputs ARE the observed pixels of the window's cells,
+    // and the regrid phase drops out.  This lane's observed column, asked for now:
+    const int fold_w = (!DIRECT && nrank == 1 && foldflag) ? foldflag[wi] : 0;   // block-uniform
+    int pixx = -1;
+    if (fold_w && lane < TX - 1 && x0 + lane < n) pixx = pcx[(long long)wi * n + x0 + lane];
 
     // -- 0. issue the loads of the occupied input tiles now (NSB per wave in registers).
     // A lane takes one row of a 32x8 tile and two 16-byte column pairs of it (columns
@@ -1225,6 +1297,23 @@ k_conv_chi2(FitK g, const double* __restrict__ iunif,
         }
       }
     }
+    // folded walkers: the observed rows of this wave's 8 cell rows, and their data
+    double fdv[R];
+    unsigned fvalid = 0u;
+#pragma unroll
+    for (int r = 0; r < R; ++r) fdv[r] = 0.0;
+    if (fold_w && wv < TY / R) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int cy = wv * R + r;
+        int jy = -1;
+        if (cy < TY - 1 && y0 + cy < n) jy = pcy[(long long)wi * n + y0 + cy];   // wave-uniform
+        if (jy >= 0) {
+          fvalid |= 1u << r;
+          if (pixx >= 0) fdv[r] = dat[(long long)jy * g.nx + pixx];
+        }
+      }
+    }
     lds_barrier();
     STAMP(2);
 
@@ -1284,8 +1373,8 @@ k_conv_chi2(FitK g, const double* __restrict__ iunif,
     }
     for (int rk = 0; !DIRECT && rk < nrank; ++rk) {
       // taps through the scalar cache (block-uniform addresses): the LDS is busy enough
-      const double* __restrict__ wxr = gxp + rk * kpad;
-      const double* __restrict__ wyr = gyp + rk * kpad;
+      const double* __restrict__ wxr = fold_w ? gxw + (long long)wi * kpad : gxp + rk * kpad;
+      const double* __restrict__ wyr = fold_w ? gyw + (long long)wi * kpad : gyp + rk * kpad;
       double res[MAXR][R];
 #pragma unroll
       for (int q = 0; q < MAXR; ++q) {
@@ -1362,72 +1451,86 @@ k_conv_chi2(FitK g, const double* __restrict__ iunif,
       }
     }
     STAMP(5);
-    // what the regrid needs from HBM, requested only now: the passes above want the registers
-    if (ix < ixb) {
-      i1 = cellx[(long long)wi * g.nx + ix] - x0;
-      t1 = fracx[(long long)wi * g.nx + ix];
-    }
-#pragma unroll
-    for (int q = 0; q < NRQ; ++q) {
-      const int jy = jya + wv + CV_NW * q;
-      const bool rowin = jy < jyb;
-      i0q[q] = rowin ? celly[(long long)wi * g.ny + jy] - y0 : -1;   // wave-uniform
-      t0q[q] = rowin ? fracy[(long long)wi * g.ny + jy] : 0.0;
-      dv[q] = (ix < ixb && rowin) ? dat[(long long)jy * g.nx + ix] : 0.0;
-    }
-    const bool xown = i1 >= 0 && i1 < TX - 1;               // else owned by another window
-    lds_barrier();                                        // column pass done reading LDS
-    if (DIRECT) {
-      double* half = lds + TY * PC;                         // the odd tap columns' sums
-      if (tapset == 1) {
-#pragma unroll
-        for (int r = 0; r < RB; ++r) half[(rb * RB + r) * PC + lane] = dacc[r];
-      }
-      lds_barrier();
-      if (tapset == 0) {
-#pragma unroll
-        for (int r = 0; r < RB; ++r)
-          lds[(rb * RB + r) * PC + lane] = dacc[r] + half[(rb * RB + r) * PC + lane];
-      }
-    } else if (wv < TY / R) {
-#pragma unroll
-      for (int r = 0; r < R; ++r) lds[(wv * R + r) * PC + lane] = acc[r];
-    }
-    lds_barrier();
-
-    STAMP(6);
-    // -- 5. regrid + chi-square sums from the LDS tile
     double gf = 0.0, ff = 0.0;
+    if (fold_w) {
+      // the column pass left cell (row wv*8 + r, column lane) of the regridded model in
+      // acc[r]: straight into sum(I*d), sum(I*I) (cells without an observed pixel add nothing)
+      if (wv < TY / R) {
 #pragma unroll
-    for (int q = 0; q < NRQ; ++q) {
-      const int jy = jya + wv + CV_NW * q;
-      if (jy < jyb) {
-        const int i0 = i0q[q];                              // wave-uniform
-        if (xown && i0 >= 0 && i0 < TY - 1) {
-          const double t0 = t0q[q];
-          const double* c = lds + i0 * PC + i1;
-          const double v00 = c[0], v01 = c[1], v10 = c[PC], v11 = c[PC + 1];
-          const double val = v00 * (1 - t0) * (1 - t1) + v01 * (1 - t0) * t1 +
-                             v10 * t0 * (1 - t1) + v11 * t0 * t1;
-          gf = fma(val, dv[q], gf);
-          ff = fma(val, val, ff);
+        for (int r = 0; r < R; ++r) {
+          const double a = (pixx >= 0 && ((fvalid >> r) & 1u)) ? acc[r] : 0.0;
+          gf = fma(a, fdv[r], gf);
+          ff = fma(a, a, ff);
         }
       }
-    }
-    // (only if the observed grid is finer than the model grid) further columns / rows
-    for (int ix2 = ix; ix2 < ixb; ix2 += 64) {
-      const int i1b = cellx[(long long)wi * g.nx + ix2] - x0;
-      if (i1b < 0 || i1b >= TX - 1) continue;
-      const double t1b = fracx[(long long)wi * g.nx + ix2];
-      for (int jy = jya + wv + (ix2 == ix ? CV_NW * NRQ : 0); jy < jyb; jy += CV_NW) {
-        const int i0 = celly[(long long)wi * g.ny + jy] - y0;
-        if (i0 < 0 || i0 >= TY - 1) continue;
-        const double t0 = fracy[(long long)wi * g.ny + jy];
-        const double* c = lds + i0 * PC + i1b;
-        const double val = c[0] * (1 - t0) * (1 - t1b) + c[1] * (1 - t0) * t1b +
-                           c[PC] * t0 * (1 - t1b) + c[PC + 1] * t0 * t1b;
-        gf = fma(val, dat[(long long)jy * g.nx + ix2], gf);
-        ff = fma(val, val, ff);
+      STAMP(6);
+    } else {
+      // what the regrid needs from HBM, requested only now: the passes above want the registers
+      if (ix < ixb) {
+        i1 = cellx[(long long)wi * g.nx + ix] - x0;
+        t1 = fracx[(long long)wi * g.nx + ix];
+      }
+  #pragma unroll
+      for (int q = 0; q < NRQ; ++q) {
+        const int jy = jya + wv + CV_NW * q;
+        const bool rowin = jy < jyb;
+        i0q[q] = rowin ? celly[(long long)wi * g.ny + jy] - y0 : -1;   // wave-uniform
+        t0q[q] = rowin ? fracy[(long long)wi * g.ny + jy] : 0.0;
+        dv[q] = (ix < ixb && rowin) ? dat[(long long)jy * g.nx + ix] : 0.0;
+      }
+      const bool xown = i1 >= 0 && i1 < TX - 1;               // else owned by another window
+      lds_barrier();                                        // column pass done reading LDS
+      if (DIRECT) {
+        double* half = lds + TY * PC;                         // the odd tap columns' sums
+        if (tapset == 1) {
+  #pragma unroll
+          for (int r = 0; r < RB; ++r) half[(rb * RB + r) * PC + lane] = dacc[r];
+        }
+        lds_barrier();
+        if (tapset == 0) {
+  #pragma unroll
+          for (int r = 0; r < RB; ++r)
+            lds[(rb * RB + r) * PC + lane] = dacc[r] + half[(rb * RB + r) * PC + lane];
+        }
+      } else if (wv < TY / R) {
+  #pragma unroll
+        for (int r = 0; r < R; ++r) lds[(wv * R + r) * PC + lane] = acc[r];
+      }
+      lds_barrier();
+
+      STAMP(6);
+      // -- 5. regrid + chi-square sums from the LDS tile
+  #pragma unroll
+      for (int q = 0; q < NRQ; ++q) {
+        const int jy = jya + wv + CV_NW * q;
+        if (jy < jyb) {
+          const int i0 = i0q[q];                              // wave-uniform
+          if (xown && i0 >= 0 && i0 < TY - 1) {
+            const double t0 = t0q[q];
+            const double* c = lds + i0 * PC + i1;
+            const double v00 = c[0], v01 = c[1], v10 = c[PC], v11 = c[PC + 1];
+            const double val = v00 * (1 - t0) * (1 - t1) + v01 * (1 - t0) * t1 +
+                               v10 * t0 * (1 - t1) + v11 * t0 * t1;
+            gf = fma(val, dv[q], gf);
+            ff = fma(val, val, ff);
+          }
+        }
+      }
+      // (only if the observed grid is finer than the model grid) further columns / rows
+      for (int ix2 = ix; ix2 < ixb; ix2 += 64) {
+        const int i1b = cellx[(long long)wi * g.nx + ix2] - x0;
+        if (i1b < 0 || i1b >= TX - 1) continue;
+        const double t1b = fracx[(long long)wi * g.nx + ix2];
+        for (int jy = jya + wv + (ix2 == ix ? CV_NW * NRQ : 0); jy < jyb; jy += CV_NW) {
+          const int i0 = celly[(long long)wi * g.ny + jy] - y0;
+          if (i0 < 0 || i0 >= TY - 1) continue;
+          const double t0 = fracy[(long long)wi * g.ny + jy];
+          const double* c = lds + i0 * PC + i1b;
+          const double val = c[0] * (1 - t0) * (1 - t1b) + c[1] * (1 - t0) * t1b +
+                             c[PC] * t0 * (1 - t1b) + c[PC + 1] * t0 * t1b;
+          gf = fma(val, dat[(long long)jy * g.nx + ix2], gf);
+          ff = fma(val, val, ff);
+        }
       }
     }
     gf = wave_sum(gf);
@@ -2234,6 +2337,11 @@ struct Scratch {
   int* livecount = nullptr;
   int* tile_ix = nullptr;
   int* tile_jy = nullptr;
+  int* foldflag = nullptr;     // [walker] the regrid folds into the beam taps (k_prep)
+  double* gxw = nullptr;       // [walker][kpad] folded row / column taps
+  double* gyw = nullptr;
+  int* pcx = nullptr;          // [walker][nneed] observed column / row inside each model cell, -1 = none
+  int* pcy = nullptr;
   // Calls that use this set are ordered: `done` is recorded behind the last
   // launch that touched it, and a call on another stream waits for it first.
   hipEvent_t done = nullptr;
@@ -2407,6 +2515,11 @@ size_t carve(const slamhip_ctx* c, size_t W, unsigned char* base, Scratch* s) {
   t.livecount = reinterpret_cast<int*>(take(64 * sizeof(int)));
   t.tile_ix = reinterpret_cast<int*>(take(W * c->fz_grid.x * 2 * sizeof(int)));
   t.tile_jy = reinterpret_cast<int*>(take(W * c->fz_grid.y * 2 * sizeof(int)));
+  t.foldflag = reinterpret_cast<int*>(take(W * sizeof(int)));
+  t.gxw = reinterpret_cast<double*>(take(W * (size_t)c->kpad * sizeof(double)));
+  t.gyw = reinterpret_cast<double*>(take(W * (size_t)c->kpad * sizeof(double)));
+  t.pcx = reinterpret_cast<int*>(take(W * n * sizeof(int)));
+  t.pcy = reinterpret_cast<int*>(take(W * n * sizeof(int)));
   if (s && base) {
     t.wgroup = s->wgroup; t.done = s->done; t.last = s->last; t.used = s->used;
     *s = t;
@@ -2597,7 +2710,8 @@ int run_model(slamhip_ctx* c, Scratch& S, const double* d_params, int nw, hipStr
     hipLaunchKernelGGL(k_prep, dim3(nw), dim3(256), 0, st, k, d_params, nw, S.wk,
                        S.cellx, S.fracx, S.celly, S.fracy, S.tile_ix,
                        S.tile_jy, (int)c->fz_grid.x, (int)c->fz_grid.y, c->fz_sx, c->fz_sy,
-                       S.winflag, (int)(k.nv * c->fz_grid.x * c->fz_grid.y), S.livecount);
+                       S.winflag, (int)(k.nv * c->fz_grid.x * c->fz_grid.y), S.livecount,
+                       S.foldflag, S.gxw, S.gyw, S.pcx, S.pcy);
   }
   {
     Timed t_(c, KID_SURFACE, st);
@@ -2740,7 +2854,8 @@ int run_group(slamhip_ctx* c, Scratch& S, const double* d_params, int nw, double
       hipLaunchKernelGGL((k_conv_chi2<TY_, MR_, DIR_>), gz, dim3(CV_NT), fz_lds, st, c->k, \
                          S.iunif, S.cellx, S.fracx, S.celly, S.fracy,       \
                          S.livelist, S.livecount, (int)c->fz_grid.x, (int)c->fz_grid.y, \
-                         S.partial, c->kpad, fz_rank, c->k.gx_pad, c->k.gy_pad, c->k.beam_ft)
+                         S.partial, c->kpad, fz_rank, c->k.gx_pad, c->k.gy_pad, c->k.beam_ft,        \
+                         S.foldflag, S.gxw, S.gyw, S.pcx, S.pcy)
       switch (c->sep_variant) {
         case 0:
           if (fz_rank) SLAM_FUSED(64, 2, false);
@@ -2748,7 +2863,8 @@ int run_group(slamhip_ctx* c, Scratch& S, const double* d_params, int nw, double
             hipLaunchKernelGGL((k_conv_chi2<64, 2, true, DIRECT_PITCH>), gz, dim3(CV_NT), fz_lds, st, c->k,
                                S.iunif, S.cellx, S.fracx, S.celly, S.fracy,
                                S.livelist, S.livecount, (int)c->fz_grid.x, (int)c->fz_grid.y,
-                               S.partial, c->kpad, fz_rank, c->k.gx_pad, c->k.gy_pad, c->k.beam_ft);
+                               S.partial, c->kpad, fz_rank, c->k.gx_pad, c->k.gy_pad, c->k.beam_ft,
+                               S.foldflag, S.gxw, S.gyw, S.pcx, S.pcy);
           else SLAM_FUSED(64, 2, true);
           break;
         case 1: if (fz_rank) SLAM_FUSED(64, 3, false); else SLAM_FUSED(64, 3, true); break;
@@ -2896,6 +3012,7 @@ int slamhip_create(const slamhip_desc* d, slamhip_ctx** out) {
     }
   c->separable = (peak != 0.0 && worst <= 1e-14 * std::fabs(peak)) ? 1 : 0;
   c->kpad = (K + CONV_R - 1) / CONV_R * CONV_R;
+  k.kpad = c->kpad;
   std::vector<double> gx(c->kpad, 0.0), gy(c->kpad, 0.0);
   c->nrank = 1;
   if (c->separable) {
@@ -3111,6 +3228,7 @@ int slamhip_create(const slamhip_desc* d, slamhip_ctx** out) {
     if (wf > 0) carve(c, wf, sp, &c->fixed);
     c->fixed.wgroup = wf;
   }
+  k.fold = (c->fused && c->fz_rank == 1 && !d->mom0decon) ? 1 : 0;   // one-term beam on the fused path
   HIP_TRY(c, hipStreamCreate(&c->stream));
   if (d->mom0decon && c->ob_ty) {
     // residual sum of every (channel, tile) when the model is zero there: this
@@ -3414,7 +3532,8 @@ static int prep_only(slamhip_ctx* c, WalkerK* hw) {
   hipLaunchKernelGGL(k_prep, dim3(1), dim3(256), 0, c->stream, k, S.params, 1, S.wk,
                      S.cellx, S.fracx, S.celly, S.fracy, S.tile_ix,
                      S.tile_jy, (int)c->fz_grid.x, (int)c->fz_grid.y, c->fz_sx, c->fz_sy,
-                     (unsigned char*)nullptr, 0, (int*)nullptr);
+                     (unsigned char*)nullptr, 0, (int*)nullptr, (int*)nullptr, (double*)nullptr,
+                     (double*)nullptr, (int*)nullptr, (int*)nullptr);
   HIP_TRY(c, hipGetLastError());
   HIP_TRY(c, hipMemcpyAsync(hw, S.wk, sizeof *hw, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
