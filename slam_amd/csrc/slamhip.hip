@@ -116,6 +116,10 @@ struct WalkerK {
   double qk[4];                  // tan^2 i - h^2                     :395
   double wmul[4];                // 2 for the doubled thin surface    :389-390
   double prof[PROF_LEN];
+  // regrid folded into the beam (k_prep): per axis (x, y) the observed pixel of model
+  // cell c is fi0 + fstep * (c - fc0), for pixels flo .. fhi
+  int fold;
+  int fc0[2], fi0[2], fstep[2], flo[2], fhi[2];
 };
 
 // ---------------------------------------------------------------------------
@@ -158,8 +162,7 @@ __global__ void k_prep(FitK g, const double* __restrict__ params, int nw,
                        double* __restrict__ fracy, int* __restrict__ tile_ix,
                        int* __restrict__ tile_jy, int ntx, int nty, int sx, int sy,
                        unsigned char* __restrict__ winflag, int winbytes, int* __restrict__ livecount,
-                       int* __restrict__ foldflag, double* __restrict__ gxw, double* __restrict__ gyw,
-                       int* __restrict__ pcx, int* __restrict__ pcy) {
+                       double* __restrict__ gxw, double* __restrict__ gyw) {
   const int w = blockIdx.x;
   if (w >= nw) return;
   if (winflag) {
@@ -172,6 +175,7 @@ __global__ void k_prep(FitK g, const double* __restrict__ params, int nw,
   const double* p = params + (long long)w * NP;
   WalkerK& o = wk[w];
   const int t = threadIdx.x;
+  if (t == 0) o.fold = 0;
   // rgi2d's query points X - xoff, Y - yoff (:481), per axis
   for (int i = t; i < g.nx; i += blockDim.x)
     regrid_cell(g.xneed, g.nneed, g.xobs[i] - p[8], &cellx[(long long)w * g.nx + i],
@@ -209,34 +213,43 @@ __global__ void k_prep(FitK g, const double* __restrict__ params, int nw,
   // convolution [1-t, t], and beam-then-regrid equals ONE pass with the K+1 taps
   // (1-t) g[u] + t g[u-1] whose outputs land on the observed pixels directly.
   // Checked per walker and axis (the offsets move t); otherwise the general path.
-  if (foldflag) {
-    __shared__ int s_first[2], s_ok;
-    if (t == 0) { s_first[0] = s_first[1] = 0x7fffffff; s_ok = g.fold; }
-    int* pc0 = pcx + (long long)w * g.nneed;
-    int* pc1 = pcy + (long long)w * g.nneed;
-    for (int c = t; c < g.nneed; c += blockDim.x) { pc0[c] = -1; pc1[c] = -1; }
+  if (gxw) {
+    __shared__ int s_first[2], s_last[2], s_cnt[2], s_ok;
+    if (t == 0) {
+      s_first[0] = s_first[1] = 0x7fffffff;
+      s_last[0] = s_last[1] = -1;
+      s_cnt[0] = s_cnt[1] = 0;
+      s_ok = g.fold;
+    }
     __syncthreads();
     for (int i = t; i < g.nx + g.ny; i += blockDim.x) {
       const bool isx = i < g.nx;
       const int ii = isx ? i : i - g.nx;
       const int cell = isx ? cellx[(long long)w * g.nx + ii] : celly[(long long)w * g.ny + ii];
-      if (cell >= 0) atomicMin(&s_first[isx ? 0 : 1], ii);
+      if (cell >= 0) {
+        atomicMin(&s_first[isx ? 0 : 1], ii);
+        atomicMax(&s_last[isx ? 0 : 1], ii);
+        atomicAdd(&s_cnt[isx ? 0 : 1], 1);
+      }
       if (cell == -2) s_ok = 0;                            // NaN query point
     }
     __syncthreads();
     bool ok = true;
     double tf[2] = {0.0, 0.0};
+    int fc0[2] = {0, 0}, fi0[2] = {0, 0}, fst[2] = {1, 1};
     for (int ax = 0; ax < 2; ++ax) {
       const int nobs = ax == 0 ? g.nx : g.ny;
       const int* cl = ax == 0 ? cellx + (long long)w * g.nx : celly + (long long)w * g.ny;
       const double* fr = ax == 0 ? fracx + (long long)w * g.nx : fracy + (long long)w * g.ny;
       const int i0 = s_first[ax];
       if (i0 >= nobs) continue;                            // no pixel inside the grid: nothing to regrid
+      if (s_cnt[ax] != s_last[ax] - i0 + 1) ok = false;    // the pixels inside the grid are one run
       const int c0 = cl[i0];
       const double t0 = fr[i0];
       tf[ax] = t0;
       const int step = (i0 + 1 < nobs && cl[i0 + 1] >= 0) ? cl[i0 + 1] - c0 : 1;
       if (step != 1 && step != -1) ok = false;
+      fc0[ax] = c0; fi0[ax] = i0; fst[ax] = step;
       for (int i = t; i < nobs; i += blockDim.x) {
         const int c = cl[i];
         if (c < 0) continue;
@@ -246,14 +259,14 @@ __global__ void k_prep(FitK g, const double* __restrict__ params, int nw,
     if (!ok) s_ok = 0;
     __syncthreads();
     const bool fold = s_ok != 0;
-    if (t == 0) foldflag[w] = fold ? 1 : 0;
-    if (fold) {
-      for (int i = t; i < g.nx + g.ny; i += blockDim.x) {  // cell -> the observed pixel inside it
-        const bool isx = i < g.nx;
-        const int ii = isx ? i : i - g.nx;
-        const int cell = isx ? cellx[(long long)w * g.nx + ii] : celly[(long long)w * g.ny + ii];
-        if (cell >= 0) (isx ? pc0 : pc1)[cell] = ii;
+    if (t == 0) {
+      o.fold = fold ? 1 : 0;
+      for (int ax = 0; ax < 2; ++ax) {
+        o.fc0[ax] = fc0[ax]; o.fi0[ax] = fi0[ax]; o.fstep[ax] = fst[ax];
+        o.flo[ax] = s_first[ax]; o.fhi[ax] = s_last[ax];   // empty run: flo > fhi
       }
+    }
+    if (fold) {
       for (int u = t; u < 2 * g.kpad; u += blockDim.x) {
         const bool isx = u < g.kpad;
         const int v = isx ? u : u - g.kpad;
@@ -984,7 +997,7 @@ k_compact(FitK g, const unsigned char* __restrict__ winflag, int total,
           const unsigned char* __restrict__ flags, int ftx, int fty,
           const int* __restrict__ tile_ix, const int* __restrict__ tile_jy,
           int wnx, int wny, int sx, int sy, int ty,
-          WinDesc* __restrict__ list, int* __restrict__ count) {
+          WinDesc* __restrict__ list, int* __restrict__ count, const WalkerK* __restrict__ wk) {
   const int e = blockIdx.x * 256 + threadIdx.x;
   // one counter update per wave (a single address takes ~1 atomic per clock):
   // lane 0 reserves the wave's slots, each live lane takes its rank among them
@@ -1059,10 +1072,31 @@ k_compact(FitK g, const unsigned char* __restrict__ winflag, int total,
     }
   }
   D->e = e;
-  D->ixa = tile_ix[((long long)wi * wnx + tbx) * 2];
-  D->ixb = tile_ix[((long long)wi * wnx + tbx) * 2 + 1];
-  D->jya = tile_jy[((long long)wi * wny + tby) * 2];
-  D->jyb = tile_jy[((long long)wi * wny + tby) * 2 + 1];
+  if (wk[wi].fold) {
+    // folded regrid: the observed pixel of the window's cell column j is ixa + (+-1) j for
+    // ja <= j < jb; ixb packs {bit 0: step +1, bits 8-15: ja, bits 16-23: jb, bit 31: folded};
+    // jya / jyb the same for rows
+    const WalkerK& w = wk[wi];
+    int out[4];
+#pragma unroll
+    for (int ax = 0; ax < 2; ++ax) {
+      const int c0 = ax == 0 ? tbx * sx : tby * sy;            // the window's first cell
+      const int ncell = min(ax == 0 ? sx : sy, n - 1 - c0);    // cells it owns
+      const int p0 = w.fi0[ax] + w.fstep[ax] * (c0 - w.fc0[ax]);
+      int ja, jb;
+      if (w.fstep[ax] > 0) { ja = max(0, w.flo[ax] - p0); jb = min(ncell, w.fhi[ax] - p0 + 1); }
+      else                 { ja = max(0, p0 - w.fhi[ax]); jb = min(ncell, p0 - w.flo[ax] + 1); }
+      if (jb < ja) jb = ja;
+      out[2 * ax] = p0;
+      out[2 * ax + 1] = (int)((w.fstep[ax] > 0 ? 1u : 0u) | ((unsigned)ja << 8) | ((unsigned)jb << 16) | 0x80000000u);
+    }
+    D->ixa = out[0]; D->ixb = out[1]; D->jya = out[2]; D->jyb = out[3];
+  } else {
+    D->ixa = tile_ix[((long long)wi * wnx + tbx) * 2];
+    D->ixb = tile_ix[((long long)wi * wnx + tbx) * 2 + 1];
+    D->jya = tile_jy[((long long)wi * wny + tby) * 2];
+    D->jyb = tile_jy[((long long)wi * wny + tby) * 2 + 1];
+  }
   D->nocc = nocc;
   D->z = z;
   D->tb = tbx | (tby << 16);
@@ -1102,8 +1136,7 @@ k_conv_chi2(FitK g, const double* __restrict__ iunif,
             double* __restrict__ partial, int kpad, int nrank,
             const double* __restrict__ gxp, const double* __restrict__ gyp,
             const double* __restrict__ gbt,
-            const int* __restrict__ foldflag, const double* __restrict__ gxw, const double* __restrict__ gyw,
-            const int* __restrict__ pcx, const int* __restrict__ pcy) {
+            const double* __restrict__ gxw, const double* __restrict__ gyw) {
   // DIRECT (nrank == 0): the beam is not worth factorising (a rotated Gaussian
   // needs ~14 terms): direct K x K taps on the staged tile instead of row +
   // column passes
@@ -1188,9 +1221,12 @@ k_conv_chi2(FitK g, const double* __restrict__ iunif,
     // Walkers whose regrid folds into the beam (k_prep): the passes below run with the
     // walker's K+1 taps, their outputs ARE the observed pixels of the window's cells,
     // and the regrid phase drops out.  This lane's observed column, asked for now:
-    const int fold_w = (!DIRECT && nrank == 1 && foldflag) ? foldflag[wi] : 0;   // block-uniform
-    int pixx = -1;
-    if (fold_w && lane < TX - 1 && x0 + lane < n) pixx = pcx[(long long)wi * n + x0 + lane];
+    // (k_compact left the pixel of the window's first cell, the direction and the range of
+    // cells that have a pixel in the descriptor's range words.)
+    const int fxw = head(2), fyw = head(4);
+    const bool fold_w = !DIRECT && fxw < 0;                 // block-uniform
+    const int fja = (fxw >> 8) & 255, fjb = (fxw >> 16) & 255;
+    const int pixx = (fold_w && lane >= fja && lane < fjb) ? head(1) + ((fxw & 1) ? lane : -lane) : -1;
 
     // -- 0. issue the loads of the occupied input tiles now (NSB per wave in registers).
     // A lane takes one row of a 32x8 tile and two 16-byte column pairs of it (columns
@@ -1232,6 +1268,23 @@ k_conv_chi2(FitK g, const double* __restrict__ iunif,
       }
     }
     const double* dat = g.data + (long long)k * g.ny * g.nx;
+    // folded walkers: the data under this wave's 8 cell rows, in flight until the end
+    double fdv[R];
+    unsigned fvalid = 0u;
+#pragma unroll
+    for (int r = 0; r < R; ++r) fdv[r] = 0.0;
+    if (fold_w && wv < TY / R) {
+      const int ya = (fyw >> 8) & 255, yb = (fyw >> 16) & 255;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int cy = wv * R + r;                          // wave-uniform
+        if (cy >= ya && cy < yb) {
+          fvalid |= 1u << r;
+          const int jy = head(3) + ((fyw & 1) ? cy : -cy);
+          if (pixx >= 0) fdv[r] = dat[(long long)jy * g.nx + pixx];
+        }
+      }
+    }
     const int ixa = head(1), ixb = head(2);
     const int jya = head(3), jyb = head(4);
     const int ix = ixa + lane;
@@ -1294,23 +1347,6 @@ k_conv_chi2(FitK g, const double* __restrict__ iunif,
           const double2* rp = reinterpret_cast<const double2*>(src + gofs);
           if (ok & 1) { const double2 v = rp[0]; tile[o] = v.x; tile[o + 1] = v.y; }
           if (ok & 2) { const double2 v = rp[8]; tile[o + 16] = v.x; tile[o + 17] = v.y; }
-        }
-      }
-    }
-    // folded walkers: the observed rows of this wave's 8 cell rows, and their data
-    double fdv[R];
-    unsigned fvalid = 0u;
-#pragma unroll
-    for (int r = 0; r < R; ++r) fdv[r] = 0.0;
-    if (fold_w && wv < TY / R) {
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const int cy = wv * R + r;
-        int jy = -1;
-        if (cy < TY - 1 && y0 + cy < n) jy = pcy[(long long)wi * n + y0 + cy];   // wave-uniform
-        if (jy >= 0) {
-          fvalid |= 1u << r;
-          if (pixx >= 0) fdv[r] = dat[(long long)jy * g.nx + pixx];
         }
       }
     }
@@ -2337,11 +2373,8 @@ struct Scratch {
   int* livecount = nullptr;
   int* tile_ix = nullptr;
   int* tile_jy = nullptr;
-  int* foldflag = nullptr;     // [walker] the regrid folds into the beam taps (k_prep)
   double* gxw = nullptr;       // [walker][kpad] folded row / column taps
   double* gyw = nullptr;
-  int* pcx = nullptr;          // [walker][nneed] observed column / row inside each model cell, -1 = none
-  int* pcy = nullptr;
   // Calls that use this set are ordered: `done` is recorded behind the last
   // launch that touched it, and a call on another stream waits for it first.
   hipEvent_t done = nullptr;
@@ -2515,11 +2548,8 @@ size_t carve(const slamhip_ctx* c, size_t W, unsigned char* base, Scratch* s) {
   t.livecount = reinterpret_cast<int*>(take(64 * sizeof(int)));
   t.tile_ix = reinterpret_cast<int*>(take(W * c->fz_grid.x * 2 * sizeof(int)));
   t.tile_jy = reinterpret_cast<int*>(take(W * c->fz_grid.y * 2 * sizeof(int)));
-  t.foldflag = reinterpret_cast<int*>(take(W * sizeof(int)));
   t.gxw = reinterpret_cast<double*>(take(W * (size_t)c->kpad * sizeof(double)));
   t.gyw = reinterpret_cast<double*>(take(W * (size_t)c->kpad * sizeof(double)));
-  t.pcx = reinterpret_cast<int*>(take(W * n * sizeof(int)));
-  t.pcy = reinterpret_cast<int*>(take(W * n * sizeof(int)));
   if (s && base) {
     t.wgroup = s->wgroup; t.done = s->done; t.last = s->last; t.used = s->used;
     *s = t;
@@ -2711,7 +2741,7 @@ int run_model(slamhip_ctx* c, Scratch& S, const double* d_params, int nw, hipStr
                        S.cellx, S.fracx, S.celly, S.fracy, S.tile_ix,
                        S.tile_jy, (int)c->fz_grid.x, (int)c->fz_grid.y, c->fz_sx, c->fz_sy,
                        S.winflag, (int)(k.nv * c->fz_grid.x * c->fz_grid.y), S.livecount,
-                       S.foldflag, S.gxw, S.gyw, S.pcx, S.pcy);
+                       S.gxw, S.gyw);
   }
   {
     Timed t_(c, KID_SURFACE, st);
@@ -2844,7 +2874,7 @@ int run_group(slamhip_ctx* c, Scratch& S, const double* d_params, int nw, double
       hipLaunchKernelGGL(k_compact, dim3((nwin + 255) / 256), dim3(256), 0, st, c->k, S.winflag, nwin,
                          S.flags, c->ftx, c->fty, S.tile_ix, S.tile_jy,
                          (int)c->fz_grid.x, (int)c->fz_grid.y, c->fz_sx, c->fz_sy, c->fz_sy + 1,
-                         S.livelist, S.livecount);
+                         S.livelist, S.livecount, S.wk);
     }
     {
       Timed t_(c, KID_CONV, st);
@@ -2855,7 +2885,7 @@ int run_group(slamhip_ctx* c, Scratch& S, const double* d_params, int nw, double
                          S.iunif, S.cellx, S.fracx, S.celly, S.fracy,       \
                          S.livelist, S.livecount, (int)c->fz_grid.x, (int)c->fz_grid.y, \
                          S.partial, c->kpad, fz_rank, c->k.gx_pad, c->k.gy_pad, c->k.beam_ft,        \
-                         S.foldflag, S.gxw, S.gyw, S.pcx, S.pcy)
+                         S.gxw, S.gyw)
       switch (c->sep_variant) {
         case 0:
           if (fz_rank) SLAM_FUSED(64, 2, false);
@@ -2864,7 +2894,7 @@ int run_group(slamhip_ctx* c, Scratch& S, const double* d_params, int nw, double
                                S.iunif, S.cellx, S.fracx, S.celly, S.fracy,
                                S.livelist, S.livecount, (int)c->fz_grid.x, (int)c->fz_grid.y,
                                S.partial, c->kpad, fz_rank, c->k.gx_pad, c->k.gy_pad, c->k.beam_ft,
-                               S.foldflag, S.gxw, S.gyw, S.pcx, S.pcy);
+                               S.gxw, S.gyw);
           else SLAM_FUSED(64, 2, true);
           break;
         case 1: if (fz_rank) SLAM_FUSED(64, 3, false); else SLAM_FUSED(64, 3, true); break;
@@ -3532,8 +3562,7 @@ static int prep_only(slamhip_ctx* c, WalkerK* hw) {
   hipLaunchKernelGGL(k_prep, dim3(1), dim3(256), 0, c->stream, k, S.params, 1, S.wk,
                      S.cellx, S.fracx, S.celly, S.fracy, S.tile_ix,
                      S.tile_jy, (int)c->fz_grid.x, (int)c->fz_grid.y, c->fz_sx, c->fz_sy,
-                     (unsigned char*)nullptr, 0, (int*)nullptr, (int*)nullptr, (double*)nullptr,
-                     (double*)nullptr, (int*)nullptr, (int*)nullptr);
+                     (unsigned char*)nullptr, 0, (int*)nullptr, (double*)nullptr, (double*)nullptr);
   HIP_TRY(c, hipGetLastError());
   HIP_TRY(c, hipMemcpyAsync(hw, S.wk, sizeof *hw, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
