@@ -26,6 +26,7 @@ HBM_PEAK = 8.0e12      # B/s, MI355X spec (MI355X_MICROARCH.md, chip-level param
 # FP64 vector peak: half of the guide's 157.3 TFLOP/s FP32 vector peak (a wave64 FP64 FMA issues in
 # 4 cycles on a SIMD-32, an FP32 one in 2): 256 CUs x 4 SIMDs x 16 FMA/clk x 2 flop x 2.4 GHz
 FP64_PEAK = 78.6e12
+FP32_PEAK = 157.3e12   # guide's chip table, vector FP32
 
 
 def main():
@@ -43,6 +44,9 @@ def main():
     ap.add_argument('--workload', default='sparse', choices=['sparse', 'dense_disk', 'envelope'],
                     help="walker set (slam_amd/synth.py): 'sparse' = the headline (example priors); "
                          "'dense_disk' / 'envelope' light most of the sky")
+    ap.add_argument('--dtype', default='f64', choices=['f64', 'f32', 'f32g'],
+                    help="arithmetic of the hot path: f64 = the reference's (the headline); f32 = float "
+                         "accumulation / beam passes with double geometry and index; f32g = float geometry too")
     ap.add_argument('--cpu-evals', type=int, default=1,
                     help='oracle evaluations timed for cpu_baseline (0 = skip)')
     ap.add_argument('--cpu-procs', type=int, default=-1,
@@ -85,7 +89,7 @@ def main():
             dist.destroy_process_group()
         return
     fit = synth.make_fit(args.config, bpa=args.bpa, scaling=args.scaling,
-                         envelope=args.workload == 'envelope')
+                         envelope=args.workload == 'envelope', precision=args.dtype)
     eng = fit.engine
     nw_total = args.walkers * world
     P = synth.walkers(nw_total, workload=args.workload) if rank == 0 else None
@@ -142,7 +146,7 @@ def main():
         dist.destroy_process_group()
 
 
-def kernel_model(eng, fit, counts, itemsize=8):
+def kernel_model(eng, fit, counts, itemsize=8, geomsize=8):
     """Per launch group: the bytes each hot kernel MUST move in this design and the
     FP64 lane-operations it executes, from slamhip_group_counts.
     Tiles are 32x8 pixels; a geometry entry is {vlos, weight} = 2 values."""
@@ -153,7 +157,7 @@ def kernel_model(eng, fit, counts, itemsize=8):
     ty = 64 if (63 + kpad)**2 * 8 + 16 * kpad <= 156 * 1024 else 32   # conv window rows (as slamhip_create picks)
     nslot = eng.nleaf                          # >= samples; padding ignored
     tile = 32 * 8 * B
-    geom = counts['geom_groups'] * 64 * 2 * B
+    geom = counts['geom_groups'] * 64 * 2 * geomsize
     by = {
         # reads each sample's coordinates once per 8 walkers, writes the stored entries + flag words
         'k_surface': -(-W // 8) * nslot * (4 + 2 * 8) + geom + W * (nslot // 64) * 4,
@@ -175,7 +179,7 @@ def kernel_model(eng, fit, counts, itemsize=8):
 
 
 def report(args, fit, eng, world, nw_total, dt, chi2, kern, psteps, counts):
-    B = 8
+    B = 8 if args.dtype == 'f64' else 4
     nv, n, nx, ny = eng.nv, eng.nneed, eng.nx, eng.ny
     bytes_eval = synth_bytes_per_eval(eng, B)
     # SURVEY.md 8d's DENSE algorithmic bytes per walker of each kernel (four stages)
@@ -189,7 +193,10 @@ def report(args, fit, eng, world, nw_total, dt, chi2, kern, psteps, counts):
         dense['k_conv'] += dense.pop('k_regrid')       # fused: conv + regrid + chi2 in one kernel
     evals_prof = args.walkers * psteps
     total_ms = sum(v[0] for v in kern.values())
-    model_b, model_f = kernel_model(eng, fit, counts) if counts else ({}, {})
+    isz = 8 if args.dtype == 'f64' else 4
+    model_b, model_f = (kernel_model(eng, fit, counts, isz, 4 if args.dtype == 'f32g' else 8)
+                        if counts else ({}, {}))
+    peak_flops = FP64_PEAK if args.dtype == 'f64' else FP32_PEAK
     groups = -(-args.walkers // eng.walkers_per_group)          # launch groups per step
     per_kernel = {}
     for name, (ms, cnt) in kern.items():
@@ -207,9 +214,9 @@ def report(args, fit, eng, world, nw_total, dt, chi2, kern, psteps, counts):
                 d['hbm_GBps'] = model_b[name] / sec / 1e9
                 d['hbm_frac'] = model_b[name] / sec / HBM_PEAK
             if name in model_f:
-                d['fp64_ops_per_launch'] = model_f[name]
+                d['fp64_ops_per_launch'] = model_f[name]      # counted operations (float ones at f32)
                 d['fp64_TFLOPs'] = model_f[name] / sec / 1e12
-                d['fp64_frac'] = model_f[name] / sec / FP64_PEAK
+                d['fp64_frac'] = model_f[name] / sec / peak_flops
         per_kernel[name] = d
     dom = max((k for k in per_kernel if k in dense), key=lambda k: kern[k][0])
     dk = per_kernel[dom]
@@ -226,7 +233,8 @@ def report(args, fit, eng, world, nw_total, dt, chi2, kern, psteps, counts):
     if 'fp64_frac' in dk:
         # the binding resource of this design is the FP64 vector pipe (arithmetic intensity
         # of the compulsory traffic is above the machine balance): fraction against THAT
-        roofline.update({'bound': 'fp64_valu', 'achieved': dk['fp64_TFLOPs'], 'peak': FP64_PEAK / 1e12,
+        roofline.update({'bound': 'fp64_valu' if args.dtype == 'f64' else 'fp32_valu',
+                         'achieved': dk['fp64_TFLOPs'], 'peak': peak_flops / 1e12,
                          'unit': 'TFLOP/s', 'frac': dk['fp64_frac'],
                          'hbm': {'achieved': dk['hbm_GBps'], 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
                                  'frac': dk['hbm_frac'], 'bytes_per_launch': dk['bytes_per_launch']},
@@ -236,14 +244,15 @@ def report(args, fit, eng, world, nw_total, dt, chi2, kern, psteps, counts):
                          'frac': None})
     return {
         'metric': 'walker chi2 evals/sec (whole node) at 512x512x128'
-                  if args.config == 'C3' and args.scaling == 'uniform' and args.workload == 'sparse'
+                  if args.config == 'C3' and args.scaling == 'uniform' and args.workload == 'sparse' and args.dtype == 'f64'
                   else f'walker chi2 evals/sec (whole node), {args.config} scaling={args.scaling} '
-                       f'workload={args.workload}',
+                       f'workload={args.workload} dtype={args.dtype}',
         'value': nw_total * args.steps / dt, 'unit': 'evals/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True,
-        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-        'config': {'workload': f'SYN-v1 {args.config} ({args.workload}): {nx}x{ny}x{nv} cube, '
+        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64' if args.dtype == 'f64' else 'f32',
+        'data': 'synthetic',
+        'config': {'workload': f'SYN-v1 {args.config} ({args.workload}, {args.dtype}): {nx}x{ny}x{nv} cube, '
                                f'{args.walkers} walkers per GPU per step, beam K={fit.gaussbeam.shape[0]} '
                                f'bpa={args.bpa:g} (beam rank {eng.beam_rank})',
                    'walkers_per_gpu': args.walkers, 'walkers_per_launch': eng.walkers_per_group,
@@ -433,7 +442,7 @@ def measured_traffic(kernel, args, eng):
     except Exception:
         return None, None
     meta = t.get('_meta', {})
-    if args.scaling != 'uniform' or args.workload != 'sparse':
+    if args.scaling != 'uniform' or args.workload != 'sparse' or args.dtype != 'f64':
         return None, None
     if (meta.get('config') != args.config or meta.get('walkers_per_launch') != eng.walkers_per_group
             or meta.get('bpa') != args.bpa):

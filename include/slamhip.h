@@ -77,6 +77,21 @@ typedef struct slamhip_desc {
                              * :345, the model is regrid -> per-pixel moment-0
                              * scale -> beam on the observed grid (:520-530)
                              * and has no global amplitude (:533-536).        */
+  int32_t precision;        /* arithmetic of the hot path (slamhip_chi2_batch*):
+                             * 0 = double (the reference's; parity 1e-9);
+                             * 1 = float: line-profile accumulation, Iunif and beam
+                             *     passes in single precision (parity 1e-3 on cubes
+                             *     and chi2).  Geometry (:382-452), the truncating
+                             *     table index (:462-463) and the sums of :486-487 /
+                             *     :601 stay in double, so every sample selects the
+                             *     reference's table entry;
+                             * 2 = as 1 with the geometry in single precision too:
+                             *     about one sample in 1e5 then lands in the
+                             *     neighbouring table entry (isolated voxels differ
+                             *     by a few percent of their value; chi2 still 1e-3).
+                             * 1 and 2: scaling 'uniform' only; slamhip_cubemodel /
+                             * _iconv apply the (double) dense beam to the
+                             * single-precision Iunif. */
 } slamhip_desc;
 
 typedef struct slamhip_ctx slamhip_ctx;

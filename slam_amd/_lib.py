@@ -35,6 +35,7 @@ class SlamhipDesc(C.Structure):
         ('gaussbeam', _dp),
         ('max_scratch_bytes', C.c_int64),
         ('mom0decon', _dp),
+        ('precision', C.c_int32),
     ]
 
 

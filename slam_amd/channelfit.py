@@ -56,8 +56,10 @@ def makemom01(d, v, sigma):
 class ChannelFit(ReadFits):
 
     def __init__(self, disk: bool = True, envelope: bool = False,
-                 scaling: str = 'uniform', progressbar: bool = True):
+                 scaling: str = 'uniform', progressbar: bool = True,
+                 precision: str = 'f64'):
         self.paramkeys = list(PARAMKEYS)
+        self.precision = precision      # extension: 'f32' runs the likelihood in single precision
         self.disk = disk
         self.envelope = envelope
         self.scaling = scaling
@@ -226,7 +228,8 @@ class ChannelFit(ReadFits):
             if not hasattr(self, 'data_valid'):
                 raise RuntimeError('call makegrid() first')
             self._engine = HipLikelihood(self.setup_dict(),
-                                         max_scratch_bytes=self._max_scratch_bytes)
+                                         max_scratch_bytes=self._max_scratch_bytes,
+                                         precision=self.precision)
         return self._engine
 
     @engine.setter

@@ -40,7 +40,6 @@ namespace {
 constexpr int NP = SLAMHIP_NPARAM;
 constexpr int PROF_LEN = SLAMHIP_PROF_LEN;   // 45
 constexpr int PROF_N = PROF_LEN - 1;         // 44 (:427)
-constexpr double VL_MASKED = 1.0e300;        // stands in for a NaN vlos
 constexpr double IDX_GUARD = 1.0e-9;         // |iv - integer| below this -> exact path
 constexpr int CH = 16;                       // channels accumulated in registers
 constexpr int CONV_TX = 64;                  // conv tile width (= one wave)
@@ -162,7 +161,8 @@ __global__ void k_prep(FitK g, const double* __restrict__ params, int nw,
                        double* __restrict__ fracy, int* __restrict__ tile_ix,
                        int* __restrict__ tile_jy, int ntx, int nty, int sx, int sy,
                        unsigned char* __restrict__ winflag, int winbytes, int* __restrict__ livecount,
-                       double* __restrict__ gxw, double* __restrict__ gyw) {
+                       double* __restrict__ gxw, double* __restrict__ gyw,
+                       float* __restrict__ gxw32, float* __restrict__ gyw32) {
   const int w = blockIdx.x;
   if (w >= nw) return;
   if (winflag) {
@@ -272,7 +272,9 @@ __global__ void k_prep(FitK g, const double* __restrict__ params, int nw,
         const int v = isx ? u : u - g.kpad;
         const double* gp = isx ? g.gx_pad : g.gy_pad;
         const double tt = tf[isx ? 0 : 1];
-        (isx ? gxw : gyw)[(long long)w * g.kpad + v] = (1.0 - tt) * gp[v] + (v > 0 ? tt * gp[v - 1] : 0.0);
+        const double tap = (1.0 - tt) * gp[v] + (v > 0 ? tt * gp[v - 1] : 0.0);
+        (isx ? gxw : gyw)[(long long)w * g.kpad + v] = tap;
+        if (gxw32) (isx ? gxw32 : gyw32)[(long long)w * g.kpad + v] = (float)tap;
       }
     }
   }
@@ -357,77 +359,114 @@ __global__ void k_prep(FitK g, const double* __restrict__ params, int nw,
 // ---------------------------------------------------------------------------
 // Geometry of one sample on one surface: update_xdisk + getvlos.
 // ---------------------------------------------------------------------------
-struct Surf { double x, r, vlos; };
+// The kernels of the hot path exist in two arithmetic types T: double (the
+// reference's, parity to 1e-9) and float (`precision` = 1 in the descriptor:
+// geometry, line-profile accumulation and beam passes in single precision,
+// 1e-3 parity; the truncating table index and the sums of :486-487, :601 stay
+// in double in both).
+template <typename T> struct Real;
+template <> struct Real<double> {
+  using vec2 = double2;
+  static constexpr double masked = 1.0e300;              // stands in for a NaN vlos
+  static constexpr double huge = 1.79769313486231570815e308;   // nan_to_num(inf), :468
+  static constexpr double beyond = 1.0 + 1e-12;          // |Y| > Rc * this: masked whatever x is
+  __device__ static double2 make2(double a, double b) { return make_double2(a, b); }
+  __device__ static double nan() { return __builtin_nan(""); }
+  // r**(-1/2) from the hardware estimate and two Newton steps (r is a finite, normal
+  // radius here: masked and NaN samples never arrive): <= 3 ulp, a third of the
+  // instructions of a square root and a division
+  __device__ static double rsqrt(double r) {
+    double y = __builtin_amdgcn_rsq(r);
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const double e = fma(-(r * y), y, 1.0);
+      y = fma(0.5 * y, e, y);
+    }
+    return y;
+  }
+  __device__ static double powneg(double r, double p) { return exp(-p * log(r)); }   // r**(-p)
+};
+template <> struct Real<float> {
+  using vec2 = float2;
+  static constexpr float masked = 1.0e30f;
+  static constexpr float huge = 3.402823466e38f;
+  static constexpr float beyond = 1.0f + 1e-5f;
+  __device__ static float2 make2(float a, float b) { return make_float2(a, b); }
+  __device__ static float nan() { return __builtin_nanf(""); }
+  __device__ static float rsqrt(float r) {
+    float y = __builtin_amdgcn_rsqf(r);
+    const float e = fmaf(-(r * y), y, 1.0f);             // one Newton step: ~1 ulp
+    return fmaf(0.5f * y, e, y);
+  }
+  __device__ static float powneg(float r, float p) { return __expf(-p * __logf(r)); }
+};
+
+template <typename T> struct Surf { T x, r, vlos; };
 
 // Deprojected minor-axis coordinate on surface s (update_xdisk, :382-410).
-__device__ inline double surface_x(const WalkerK& w, int s, double X, double Y) {
+template <typename T>
+__device__ inline T surface_x(const WalkerK& w, int s, T X, T Y) {
   const int kind = w.kind[s];
-  const double hh = w.h2[s];
-  if (kind == 1) return X / w.cosi;                        // :389
-  const double Xc = X * w.cosi;                            // :392
-  const double b = (1.0 + hh) * Xc;                        // :394
-  const double c = w.qk[s] * (Xc * Xc) - hh * (Y * Y);     // :395-396
-  if (kind == 2) return Xc + c / b / 2.0;                  // :398
-  const double a = w.qa[s];
-  const double D = b * b - a * c;                          // :403
-  if (!(D >= 0)) return __builtin_nan("");
-  const double rt = sqrt(D);
-  return Xc + (kind == 3 ? (b + rt) : (b - rt)) * w.iqa[s];   // :405-408
+  const T hh = (T)w.h2[s];
+  if (kind == 1) return X / (T)w.cosi;                     // :389
+  const T Xc = X * (T)w.cosi;                              // :392
+  const T b = ((T)1 + hh) * Xc;                            // :394
+  const T c = (T)w.qk[s] * (Xc * Xc) - hh * (Y * Y);       // :395-396
+  if (kind == 2) return Xc + c / b / (T)2;                 // :398
+  const T a = (T)w.qa[s];
+  const T D = b * b - a * c;                               // :403
+  if (!(D >= 0)) return Real<T>::nan();
+  const T rt = sqrt(D);
+  return Xc + (kind == 3 ? (b + rt) : (b - rt)) * (T)w.iqa[s];   // :405-408
 }
 
 // True where getvlos (:443-447) leaves NaN whatever the velocity is.
-__device__ inline bool surface_masked(const FitK& g, const WalkerK& w, double r) {
-  const bool outer = r > w.Rc;                             // :434
-  return !(r == r) || r < w.Rin || (!g.envelope && outer) || (!g.disk && !outer);
+template <typename T>
+__device__ inline bool surface_masked(const FitK& g, const WalkerK& w, T r) {
+  const bool outer = r > (T)w.Rc;                          // :434
+  return !(r == r) || r < (T)w.Rin || (!g.envelope && outer) || (!g.disk && !outer);
 }
 
 // Line-of-sight velocity for Mstar = 1 at (x, Y), radius r (getvlos, :433-447).
-__device__ inline double surface_vlos(const FitK& g, const WalkerK& w, int s,
-                                      double x, double Y, double r) {
-  const bool outer = r > w.Rc;                             // :434
-  // r**(-1/2) from the hardware estimate and two Newton steps (r is a finite, normal
-  // radius here: masked and NaN samples never arrive), 1/r as its square: <= 3 ulp,
-  // a third of the instructions of a square root and two divisions
-  double rmh = __builtin_amdgcn_rsq(r);
-#pragma unroll
-  for (int it = 0; it < 2; ++it) {
-    const double e = fma(-(r * rmh), rmh, 1.0);
-    rmh = fma(0.5 * rmh, e, rmh);
-  }
-  const double ir = rmh * rmh;
-  double vp = rmh * w.hfac[s];                             // :435
-  double vr = r * 0.0;                                     // :436
+template <typename T>
+__device__ inline T surface_vlos(const FitK& g, const WalkerK& w, int s, T x, T Y, T r) {
+  const bool outer = r > (T)w.Rc;                          // :434
+  const T rmh = Real<T>::rsqrt(r);                         // r**(-1/2); 1/r as its square
+  const T ir = rmh * rmh;
+  T vp = rmh * (T)w.hfac[s];                               // :435
+  T vr = r * (T)0;                                         // :436
   if (g.envelope && outer) {
-    vp = sqrt(w.Rc) * ir;                                  // :438
-    vr = -rmh * sqrt(2.0 - w.Rc * ir);                     // :439
+    vp = sqrt((T)w.Rc) * ir;                               // :438
+    vr = -rmh * sqrt((T)2 - (T)w.Rc * ir);                 // :439
   }
-  const double erot = Y * g.signmajor * ir;                // :440
+  const T erot = Y * (T)g.signmajor * ir;                  // :440
   if (!(g.envelope && outer))                              // vr = 0: vr*erad adds (+-)0 for the finite r > 0 that get here
-    return (vp * erot + vr) * w.sini * g.vunit;
-  const double erad = x * g.signminor * ir;                // :441
-  return (vp * erot + vr * erad) * w.sini * g.vunit;       // :442
+    return (vp * erot + vr) * (T)w.sini * (T)g.vunit;
+  const T erad = x * (T)g.signminor * ir;                  // :441
+  return (vp * erot + vr * erad) * (T)w.sini * (T)g.vunit; // :442
 }
 
-__device__ inline Surf surface_eval(const FitK& g, const WalkerK& w, int s,
-                                    double X, double Y) {
-  Surf o;
-  o.x = surface_x(w, s, X, Y);
+template <typename T>
+__device__ inline Surf<T> surface_eval(const FitK& g, const WalkerK& w, int s, T X, T Y) {
+  Surf<T> o;
+  o.x = surface_x<T>(w, s, X, Y);
   // hypot without the overflow rescaling (|x|,|Y| are grid coordinates): <= 1 ulp
   o.r = sqrt(fma(o.x, o.x, Y * Y));                        // :433
-  o.vlos = surface_masked(g, w, o.r) ? __builtin_nan("") : surface_vlos(g, w, s, o.x, Y, o.r);
+  o.vlos = surface_masked<T>(g, w, o.r) ? Real<T>::nan() : surface_vlos<T>(g, w, s, o.x, Y, o.r);
   return o;
 }
 
 constexpr int SURF_WPT = 8;   // walkers per k_surface thread
 
 // k_surface: thread per (SURF_WPT walkers, surviving sample).  Writes, per live surface,
-//   vl = vlos*sqrt(Mstar)          (1e300 where the reference has NaN)
+//   vl = vlos*sqrt(Mstar)          (Real<T>::masked where the reference has NaN)
 //   wt = intensity weight * layer-merge weight 4^-layer
 // as one {vl, wt} pair laid out [walker][surface][slot]; slots are ordered per
 // 32x8 pixel tile as [sample rank][pixel] so k_profile's lanes (= pixels) read
-// consecutive 16-B entries for every rank.
+// consecutive entries for every rank.
+template <typename T>
 __global__ void __launch_bounds__(256)
-k_surface(FitK g, const WalkerK* __restrict__ wk, double2* __restrict__ geom,
+k_surface(FitK g, const WalkerK* __restrict__ wk, typename Real<T>::vec2* __restrict__ geom,
           unsigned* __restrict__ gflag, float2* __restrict__ grange, int nw) {
   const long long leaf = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // slot
   if (leaf >= g.nslot) return;                             // whole waves: nslot is a multiple of 256
@@ -435,21 +474,22 @@ k_surface(FitK g, const WalkerK* __restrict__ wk, double2* __restrict__ geom,
   const bool pad = code == LEAF_PAD;                       // slot without a sample: an entry that adds nothing
   const int l = code >> 28, j = (code >> 14) & 0x3fff, i = code & 0x3fff;
   const long long idx = pad ? 0 : ((long long)l * g.npix + j) * g.npix + i;
-  const double X0 = g.Xnest0[idx], Y0 = g.Ynest0[idx];
+  const T X0 = (T)g.Xnest0[idx], Y0 = (T)g.Ynest0[idx];
+  constexpr T MASKED = Real<T>::masked;
   // the sample's coordinates serve SURF_WPT walkers
   for (int wi = blockIdx.z * SURF_WPT, we = min(wi + SURF_WPT, nw); wi < we; ++wi) {
   const WalkerK& w = wk[wi];
-  const double X = X0 * w.cp - Y0 * w.sp;                  // utils.py:355
-  const double Y = X0 * w.sp + Y0 * w.cp;                  // utils.py:356
-  const double lw = 1.0 / (double)(1 << (2 * (pad ? 0 : l)));   // avefour nesting :469-471
-  double pXc = 0.0, pb = 0.0, prt = 0.0;                   // root '+' leaves these for root '-' (same h)
+  const T X = X0 * (T)w.cp - Y0 * (T)w.sp;                 // utils.py:355
+  const T Y = X0 * (T)w.sp + Y0 * (T)w.cp;                 // utils.py:356
+  const T lw = (T)1 / (T)(1 << (2 * (pad ? 0 : l)));       // avefour nesting :469-471
+  T pXc = 0, pb = 0, prt = 0;                              // root '+' leaves these for root '-' (same h)
   // Most of the sky is masked (r > Rc, r < Rin): a wave whose 64 entries of a
   // surface all add nothing stores none of them and clears that surface's bit in
   // the wave's flag word, which k_profile reads before it asks for the entries.
   unsigned fm = 0;
   // r = hypot(x, Y) >= |Y|: without an envelope a sample with |Y| > Rc is masked on
   // every surface whatever x is (:443-447); a wave of such samples is done here
-  const bool beyond = !g.envelope && fabs(Y) > w.Rc * (1.0 + 1e-12);
+  const bool beyond = !g.envelope && fabs(Y) > (T)w.Rc * Real<T>::beyond;
   if (__ballot(!pad && !beyond) == 0ull) {
     if ((threadIdx.x & 63) == 0) {
       gflag[(long long)wi * (g.nslot >> 6) + (leaf >> 6)] = 0u;
@@ -459,39 +499,39 @@ k_surface(FitK g, const WalkerK* __restrict__ wk, double2* __restrict__ geom,
   }
   float vlo = 3.0e38f, vhi = -3.0e38f;                     // range of the stored vl of this lane
   for (int s = 0; s < w.nsurf; ++s) {
-    double xs;
+    T xs;
     if (w.kind[s] == 3) {                                  // :392-405, as surface_x
-      pXc = X * w.cosi;
-      pb = (1.0 + w.h2[s]) * pXc;
-      const double c = w.qk[s] * (pXc * pXc) - w.h2[s] * (Y * Y);
-      const double D = pb * pb - w.qa[s] * c;
-      prt = D >= 0 ? sqrt(D) : __builtin_nan("");
-      xs = pXc + (pb + prt) * w.iqa[s];
+      pXc = X * (T)w.cosi;
+      pb = ((T)1 + (T)w.h2[s]) * pXc;
+      const T c = (T)w.qk[s] * (pXc * pXc) - (T)w.h2[s] * (Y * Y);
+      const T D = pb * pb - (T)w.qa[s] * c;
+      prt = D >= 0 ? sqrt(D) : Real<T>::nan();
+      xs = pXc + (pb + prt) * (T)w.iqa[s];
     } else if (w.kind[s] == 4) {                           // :408, always right after its root '+'
-      xs = pXc + (pb - prt) * w.iqa[s];
+      xs = pXc + (pb - prt) * (T)w.iqa[s];
     } else {
-      xs = surface_x(w, s, X, Y);
+      xs = surface_x<T>(w, s, X, Y);
     }
-    const double r = sqrt(fma(xs, xs, Y * Y));             // :433
-    double vl = VL_MASKED, wt = 0.0;
-    if (!pad && !surface_masked(g, w, r)) {                // else NaN vlos: most of the sky
-      vl = surface_vlos(g, w, s, xs, Y, r) * w.sqrtM;      // :460
-      wt = (r < w.Rc ? 1.0 : w.Ienv) * w.inv_ienv1;        // :465
-      if (w.pI != 0.0) wt = wt * exp(-w.pI * log(r));      // r**(-pI), :466-467
-      wt = wt * (lw * w.wmul[s]);
+    const T r = sqrt(fma(xs, xs, Y * Y));                  // :433
+    T vl = MASKED, wt = 0;
+    if (!pad && !surface_masked<T>(g, w, r)) {             // else NaN vlos: most of the sky
+      vl = surface_vlos<T>(g, w, s, xs, Y, r) * (T)w.sqrtM;   // :460
+      wt = (r < (T)w.Rc ? (T)1 : (T)w.Ienv) * (T)w.inv_ienv1;  // :465
+      if (w.pI != 0.0) wt = wt * Real<T>::powneg(r, (T)w.pI);  // r**(-pI), :466-467
+      wt = wt * (lw * (T)w.wmul[s]);
       if (!(vl == vl) || !(wt == wt)) {                    // NaN -> contributes 0 (:463,:468)
-        vl = VL_MASKED;
-        wt = 0.0;
+        vl = MASKED;
+        wt = 0;
       } else {
-        if (fabs(vl) > VL_MASKED) vl = VL_MASKED;
-        if (fabs(wt) > 1.79769313486231570815e308)         // nan_to_num(inf) :468
-          wt = copysign(1.79769313486231570815e308, wt);
+        if (fabs(vl) > MASKED) vl = MASKED;
+        if (fabs(wt) > Real<T>::huge)                      // nan_to_num(inf) :468
+          wt = copysign(Real<T>::huge, wt);
       }
     }
-    if (__ballot(wt != 0.0 && vl != VL_MASKED) != 0ull) {  // wave-uniform
-      geom[((long long)wi * 4 + s) * g.nslot + leaf] = make_double2(vl, wt);
+    if (__ballot(wt != (T)0 && vl != MASKED) != 0ull) {    // wave-uniform
+      geom[((long long)wi * 4 + s) * g.nslot + leaf] = Real<T>::make2(vl, wt);
       fm |= 1u << s;
-      if (wt != 0.0 && vl != VL_MASKED) {
+      if (wt != (T)0 && vl != MASKED) {
         // single precision, widened by more than its rounding: only k_plan's cull reads it
         const float f = (float)vl, e = fabsf(f) * 2.4e-7f + 1.0e-30f;
         vlo = fminf(vlo, f - e);
@@ -522,7 +562,7 @@ __global__ void k_surface_tap(FitK g, const WalkerK* __restrict__ wk, int s,
   const double X0 = g.Xnest0[idx], Y0 = g.Ynest0[idx];
   const double X = X0 * w.cp - Y0 * w.sp;
   const double Y = X0 * w.sp + Y0 * w.cp;
-  const Surf f = surface_eval(g, w, s, X, Y);
+  const Surf<double> f = surface_eval<double>(g, w, s, X, Y);
   x_out[idx] = f.x;
   v_out[idx] = f.vlos;
 }
@@ -622,13 +662,18 @@ k_plan(FitK g, const WalkerK* __restrict__ wk, const float2* __restrict__ grange
 // channel, 32x8 tile) gets an occupancy byte and only occupied tiles are
 // written.  Consumers either honour the flags (k_conv_chi2) or are handed a
 // pre-zeroed buffer (dense taps).
-template <bool FAST>
+template <bool FAST, typename T, typename TG>   // T: table and accumulators, TG: geometry entries
 __global__ void __launch_bounds__(256)
-k_profile(FitK g, const WalkerK* __restrict__ wk, const double2* __restrict__ geom,
-          const unsigned* __restrict__ gflag, double* __restrict__ iunif, unsigned char* __restrict__ flags, int ftx, int fty,
+k_profile(FitK g, const WalkerK* __restrict__ wk, const typename Real<TG>::vec2* __restrict__ geom,
+          const unsigned* __restrict__ gflag, T* __restrict__ iunif, unsigned char* __restrict__ flags, int ftx, int fty,
           unsigned char* __restrict__ winflag, int wnx, int wny, int wsx, int wsy,
           const uint2* __restrict__ items, const int* __restrict__ nitems) {
-  __shared__ double s_prof[PROF_LEN];
+  using T2 = typename Real<TG>::vec2;
+  // double geometry: the reference's table entry, bit for bit (lanes near a table
+  // boundary redo the index in the reference's operation order); float geometry
+  // cannot tell, its fast index is the index
+  constexpr bool EXACT = sizeof(TG) == 8;
+  __shared__ T s_prof[PROF_LEN];
   __shared__ unsigned s_mask[4];
   // One workgroup per listed (walker, tile, channel block); the grid is sized for
   // every triple, workgroups past the end of k_plan's list leave at once.
@@ -648,7 +693,7 @@ k_profile(FitK g, const WalkerK* __restrict__ wk, const double2* __restrict__ ge
   const int tby = tile / ftx, tbx = tile - tby * ftx;
   const WalkerK& w = wk[wi];
   const int tid = threadIdx.x;
-  if (tid < PROF_LEN) s_prof[tid] = w.prof[tid];
+  if (tid < PROF_LEN) s_prof[tid] = (T)w.prof[tid];
   const int n = g.nneed;
   const int npx = n * n;
   const int x = tbx * PT_X + (tid & (PT_X - 1));
@@ -659,7 +704,7 @@ k_profile(FitK g, const WalkerK* __restrict__ wk, const double2* __restrict__ ge
   const int nsurf = w.nsurf;
   const double rinv = w.rinv, hw = w.halfwidth, voff = w.voff;
   // this thread's first slot; rank i of surface s is at gw[s*nslot + i*256]
-  const double2* gw = geom + (long long)wi * 4 * g.nslot + g.tile_goff[tile] + tid;
+  const T2* gw = geom + (long long)wi * 4 * g.nslot + g.tile_goff[tile] + tid;
   const long long ftile = ntile;
   unsigned char* fl = flags + (long long)wi * g.nv * ftile + tile;
   // k_surface's flag word of this wave's 64 samples of a rank: bit s = surface s
@@ -675,9 +720,9 @@ k_profile(FitK g, const WalkerK* __restrict__ wk, const double2* __restrict__ ge
     const double cmid = 0.5 * (g.ch_vmin[cix] + g.ch_vmax[cix]);
     const double hwc = hw + 0.5 * (g.ch_vmax[cix] - g.ch_vmin[cix]);
     const double* vk = g.vpad + cix * CH;
-    double acc[CH];
+    T acc[CH];
 #pragma unroll
-    for (int c = 0; c < CH; ++c) acc[c] = 0.0;
+    for (int c = 0; c < CH; ++c) acc[c] = 0;
     bool hit = false;
     double vks[CH];                                       // this block's channel velocities (scalar)
 #pragma unroll
@@ -690,8 +735,9 @@ k_profile(FitK g, const WalkerK* __restrict__ wk, const double2* __restrict__ ge
 #pragma unroll
     for (int c = 0; c < CH; ++c) tks[c] = FAST ? tkp[c] : 0.0;
     // one stored {vlos, weight} entry into the block's 16 channels
-    auto lookups = [&](const double vl, const double wt) {
-      const double o = vl + voff;
+    auto lookups = [&](const TG vl, const TG wtg) {
+      const T wt = (T)wtg;
+      const double o = (double)vl + voff;                 // the index arithmetic is double in both types
       if (fabs(o - cmid) > hwc) return;                   // no channel of this block is lit
       hit = true;
       // table index of every channel, fast form (differs from the reference's
@@ -713,12 +759,12 @@ k_profile(FitK g, const WalkerK* __restrict__ wk, const double2* __restrict__ ge
           lowest = min(lowest, (unsigned)__double2loint(sum));
           idx[c] = __double2hiint(sum);
         }
-        near = lowest < 2u * IDX_FGUARD;
+        near = EXACT && lowest < 2u * IDX_FGUARD;          // float: the fast index is the index
       } else {
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
           const double t = fma(vks[c] - o, rinv, 22.5);
-          near |= fabs(t - rint(t)) < IDX_GUARD;
+          near |= EXACT && fabs(t - rint(t)) < IDX_GUARD;
           idx[c] = (int)t;                                // saturating; NaN -> 0
         }
       }
@@ -726,7 +772,7 @@ k_profile(FitK g, const WalkerK* __restrict__ wk, const double2* __restrict__ ge
         // iv = ((v_valid - vlos) - voff) / dv / prof_d + prof_n//2 + 0.5   (:461-462)
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
-          double v = (FAST ? vk[c] : vks[c]) - vl;
+          double v = (FAST ? vk[c] : vks[c]) - (double)vl;
           v = v - voff;
           const int ix = (int)(v / g.dv / w.prof_d + 22.0 + 0.5);
           acc[c] = fma(s_prof[min(max(ix, 0), PROF_N)], wt, acc[c]);
@@ -744,10 +790,10 @@ k_profile(FitK g, const WalkerK* __restrict__ wk, const double2* __restrict__ ge
     // loads in flight was tried: 29.8 instead of 28.2 us/eval.)
     unsigned fcur = 0, fnxt = __builtin_amdgcn_readfirstlane(f0v);
     unsigned fnn = f1v;
-    double2 q[4], qn[4];
+    T2 q[4], qn[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s)
-      qn[s] = ((fnxt >> s) & 1u) ? gw[(long long)s * g.nslot] : make_double2(VL_MASKED, 0.0);
+      qn[s] = ((fnxt >> s) & 1u) ? gw[(long long)s * g.nslot] : Real<TG>::make2(Real<TG>::masked, (TG)0);
     for (int i = 0; i < nl; ++i) {
 #pragma unroll
       for (int s = 0; s < 4; ++s) q[s] = qn[s];
@@ -757,7 +803,7 @@ k_profile(FitK g, const WalkerK* __restrict__ wk, const double2* __restrict__ ge
         fnn = i + 2 < nl ? gf[(i + 2) * 4] : 0u;
 #pragma unroll
         for (int s = 0; s < 4; ++s)
-          qn[s] = ((fnxt >> s) & 1u) ? gw[(long long)s * g.nslot + (i + 1) * 256] : make_double2(VL_MASKED, 0.0);
+          qn[s] = ((fnxt >> s) & 1u) ? gw[(long long)s * g.nslot + (i + 1) * 256] : Real<TG>::make2(Real<TG>::masked, (TG)0);
       }
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
@@ -768,7 +814,7 @@ k_profile(FitK g, const WalkerK* __restrict__ wk, const double2* __restrict__ ge
     if (!__syncthreads_or(hit)) return;                   // empty sky after all: the flags stay 0
     unsigned m = 0;
 #pragma unroll
-    for (int c = 0; c < CH; ++c) m |= (unsigned)(acc[c] != 0.0) << c;
+    for (int c = 0; c < CH; ++c) m |= (unsigned)(acc[c] != (T)0) << c;
     m = wave_or(m);
     if ((tid & 63) == 0) s_mask[tid >> 6] = m;
     __syncthreads();
@@ -786,7 +832,7 @@ k_profile(FitK g, const WalkerK* __restrict__ wk, const double2* __restrict__ ge
           for (int bx = wbx0; bx <= wbx1; ++bx) wf[by * wnx + bx] = 1;
       }
     }
-    double* out = iunif + (long long)wi * g.nv * npx + pix;
+    T* out = iunif + (long long)wi * g.nv * npx + pix;
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
       const int k = cix * CH + c;
@@ -1127,20 +1173,22 @@ __device__ __forceinline__ void lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-template <int TY, int MAXR, bool DIRECT, int PITCH = 0>   // PITCH: LDS tile pitch fixed at compile time (0: from kpad)
+template <int TY, int MAXR, bool DIRECT, int PITCH = 0, typename T = double>   // T: arithmetic type of tile and passes; PITCH: LDS tile pitch fixed at compile time (0: from kpad)
 __global__ void __launch_bounds__(CV_NT, 4)
-k_conv_chi2(FitK g, const double* __restrict__ iunif,
+k_conv_chi2(FitK g, const T* __restrict__ iunif,
             const int* __restrict__ cellx, const double* __restrict__ fracx,
             const int* __restrict__ celly, const double* __restrict__ fracy,
             const WinDesc* __restrict__ list, int* __restrict__ count, int wnx, int wny,
             double* __restrict__ partial, int kpad, int nrank,
-            const double* __restrict__ gxp, const double* __restrict__ gyp,
-            const double* __restrict__ gbt,
-            const double* __restrict__ gxw, const double* __restrict__ gyw) {
+            const T* __restrict__ gxp, const T* __restrict__ gyp,
+            const T* __restrict__ gbt,
+            const T* __restrict__ gxw, const T* __restrict__ gyw) {
   // DIRECT (nrank == 0): the beam is not worth factorising (a rotated Gaussian
   // needs ~14 terms): direct K x K taps on the staged tile instead of row +
   // column passes
-  extern __shared__ double lds[];
+  extern __shared__ unsigned char lds_raw[];
+  T* const lds = reinterpret_cast<T*>(lds_raw);
+  using T2 = typename Real<T>::vec2;
   constexpr int TX = CONV_TX, R = CONV_R, PC = TX + 1, P2 = TX + 1;
   constexpr bool direct = DIRECT;
   constexpr int NRQ = (TY - 1 + CV_NW - 1) / CV_NW;         // regrid rows per wave
@@ -1159,10 +1207,10 @@ k_conv_chi2(FitK g, const double* __restrict__ iunif,
   // the row-pass output overlays the input tile; with several the tile must
   // survive, so the intermediate gets LDS of its own.
   // taps sit after the tile; DIRECT also parks two TY x PC half sums in the tile's place
-  double* wxl = lds + (DIRECT ? max(rows * P + 1, 2 * TY * PC) : rows * P + 1);   // [nrank][kpad] flipped taps, zero padded
-  double* wyl = wxl + nrank * kpad;
-  double* tmp = nrank == 1 ? lds : wyl + nrank * kpad;      // [rows][P2]
-  for (int e = tid; e < nrank * kpad; e += CV_NT) { wxl[e] = g.gx_pad[e]; wyl[e] = g.gy_pad[e]; }
+  T* wxl = lds + (DIRECT ? max(rows * P + 1, 2 * TY * PC) : rows * P + 1);   // [nrank][kpad] flipped taps, zero padded
+  T* wyl = wxl + nrank * kpad;
+  T* tmp = nrank == 1 ? lds : wyl + nrank * kpad;      // [rows][P2]
+  for (int e = tid; e < nrank * kpad; e += CV_NT) { wxl[e] = (T)g.gx_pad[e]; wyl[e] = (T)g.gy_pad[e]; }
   __syncthreads();
   const int nlive = *count;
   constexpr int DW = sizeof(WinDesc) / 4;                   // descriptor dwords
@@ -1212,7 +1260,7 @@ k_conv_chi2(FitK g, const double* __restrict__ iunif,
     const int tb = head(7);
     const int tby = tb >> 16, tbx = tb & 0xffff;
     const int wi = z / g.nv, k = z - wi * g.nv;
-    const double* src = iunif + (long long)z * n * n;
+    const T* src = iunif + (long long)z * n * n;
     const int x0 = tbx * (TX - 1), y0 = tby * (TY - 1);
     const int wx0 = x0 - ng, wy0 = y0 - ng;                 // window origin (image coords)
     const int ftx0 = max(wx0, 0) / PT_X, fty0 = max(wy0, 0) / PT_Y;
@@ -1236,7 +1284,7 @@ k_conv_chi2(FitK g, const double* __restrict__ iunif,
     // the tile (a pair may spill one column into the pad on either side: column -1 is
     // never read, column vcols only against zero taps).
     const int woff = wx0 & 1;
-    double* tile = lds + woff;
+    T* tile = lds + woff;
     const int prow = lane >> 3, pcol = (lane & 7) * 2;
     // position of tile (fyy, fxx) for this lane: LDS offset of its first pair, or -1;
     // bit 0 / 1 of `ok`: first / second pair inside the window
@@ -1250,19 +1298,19 @@ k_conv_chi2(FitK g, const double* __restrict__ iunif,
       gofs = gy * n + gx;
       return rr * P + cc;
     };
-    double2 sa[NSB], sb[NSB];
+    T2 sa[NSB], sb[NSB];
     int sofs[NSB], sok[NSB];
 #pragma unroll
     for (int u = 0; u < NSB; ++u) {
       const int bq = wv + CV_NW * u;
       sok[u] = 0;
       sofs[u] = 0;
-      sa[u] = sb[u] = make_double2(0.0, 0.0);
+      sa[u] = sb[u] = Real<T>::make2((T)0, (T)0);
       if (bq < nocc && bq < WIN_IDS) {
         const int q = (int)__builtin_amdgcn_readlane(idv, bq);             // wave-uniform
         int gofs;
         sofs[u] = tile_pos(q >> 8, q & 255, gofs, sok[u]);
-        const double2* rp = reinterpret_cast<const double2*>(src + gofs);
+        const T2* rp = reinterpret_cast<const T2*>(src + gofs);
         if (sok[u] & 1) sa[u] = rp[0];
         if (sok[u] & 2) sb[u] = rp[8];
       }
@@ -1315,9 +1363,9 @@ k_conv_chi2(FitK g, const double* __restrict__ iunif,
       for (int rr = wv; rr < rows; rr += CV_NW) {
         const unsigned long long mw = rr < 64 ? m0 : rr < 128 ? m1 : rr < 192 ? m2 : m3;
         if (!direct && !((mw >> (rr & 63)) & 1ull)) continue;   // wave-uniform; direct taps read every row
-        double* rowp = lds + rr * P;
+        T* rowp = lds + rr * P;
         for (int c2 = lane * 2; c2 < P; c2 += 128) {
-          if (c2 + 1 < P) { rowp[c2] = 0.0; rowp[c2 + 1] = 0.0; } else rowp[c2] = 0.0;
+          if (c2 + 1 < P) { rowp[c2] = 0; rowp[c2 + 1] = 0; } else rowp[c2] = 0;
         }
       }
     }
@@ -1344,9 +1392,9 @@ k_conv_chi2(FitK g, const double* __restrict__ iunif,
           const int fyy = q / fnx;
           int gofs, ok;
           const int o = tile_pos(fyy, q - fyy * fnx, gofs, ok);
-          const double2* rp = reinterpret_cast<const double2*>(src + gofs);
-          if (ok & 1) { const double2 v = rp[0]; tile[o] = v.x; tile[o + 1] = v.y; }
-          if (ok & 2) { const double2 v = rp[8]; tile[o + 16] = v.x; tile[o + 17] = v.y; }
+          const T2* rp = reinterpret_cast<const T2*>(src + gofs);
+          if (ok & 1) { const T2 v = rp[0]; tile[o] = v.x; tile[o + 1] = v.y; }
+          if (ok & 2) { const T2 v = rp[8]; tile[o + 16] = v.x; tile[o + 17] = v.y; }
         }
       }
     }
@@ -1357,24 +1405,24 @@ k_conv_chi2(FitK g, const double* __restrict__ iunif,
     //         tmp[row][x] = sum_u gxf[u] tile[row][x+u]   (wave <-> R output columns,
     //         lanes <-> rows; odd pitch: conflict-free), then column pass
     //         out[y][x] += sum_u gyf[u] tmp[y+u][x]        (lanes <-> x, waves <-> y blocks)
-    double acc[R];
+    T acc[R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) acc[r] = 0.0;
+    for (int r = 0; r < R; ++r) acc[r] = 0;
     // direct taps: wave <-> (block of RB output rows, half of the tap columns);
     // the two halves are added through LDS afterwards
     constexpr int RB = TY == 64 ? 2 * R : R;
     static_assert(TY / RB == CV_NW / 2, "four row blocks, two tap-column halves");
     const int rb = wv % (TY / RB), tapset = wv / (TY / RB);
-    double dacc[DIRECT ? RB : 1];
+    T dacc[DIRECT ? RB : 1];
     if (DIRECT) {
 #pragma unroll
-      for (int r = 0; r < RB; ++r) dacc[r] = 0.0;
+      for (int r = 0; r < RB; ++r) dacc[r] = 0;
       // out[y][x] = sum_{a,b} beam[K-1-a][K-1-b] tile[y+a][x+b]: per tap column b a
       // sliding pass along y (lanes <-> x; RB+R-1 tile reads and R tap reads per
       // RB*R multiply-adds); tap blocks over rows without emission are skipped
       for (int b = tapset; b < K; b += 2) {
-        const double* __restrict__ wb = gbt + b * kpad;     // block-uniform address: scalar loads
-        const double* col = tile + (rb * RB) * P + lane + b;
+        const T* __restrict__ wb = gbt + b * kpad;     // block-uniform address: scalar loads
+        const T* col = tile + (rb * RB) * P + lane + b;
         for (int u0 = 0; u0 < kpad; u0 += R) {
           const int ra = rb * RB + u0;
           unsigned long long bits = 0ull;
@@ -1391,16 +1439,16 @@ k_conv_chi2(FitK g, const double* __restrict__ iunif,
           int o1 = P, o2 = 2 * P;
           asm volatile("" : "+v"(o1));
           asm volatile("" : "+v"(o2));
-          const double* c0 = col + u0 * P;
-          const double* c1 = c0 + o1;
-          const double* c2 = c0 + o2;
-          double win[RB + R - 1];
+          const T* c0 = col + u0 * P;
+          const T* c1 = c0 + o1;
+          const T* c2 = c0 + o2;
+          T win[RB + R - 1];
 #pragma unroll
           for (int r = 0; r < RB + R - 1; ++r)
             win[r] = (r % 3 == 0 ? c0 : r % 3 == 1 ? c1 : c2)[(r / 3) * 3 * P];
 #pragma unroll
           for (int qq = 0; qq < R; ++qq) {
-            const double wgt = wb[u0 + qq];
+            const T wgt = wb[u0 + qq];
 #pragma unroll
             for (int r = 0; r < RB; ++r) dacc[r] = fma(wgt, win[r + qq], dacc[r]);
           }
@@ -1409,25 +1457,25 @@ k_conv_chi2(FitK g, const double* __restrict__ iunif,
     }
     for (int rk = 0; !DIRECT && rk < nrank; ++rk) {
       // taps through the scalar cache (block-uniform addresses): the LDS is busy enough
-      const double* __restrict__ wxr = fold_w ? gxw + (long long)wi * kpad : gxp + rk * kpad;
-      const double* __restrict__ wyr = fold_w ? gyw + (long long)wi * kpad : gyp + rk * kpad;
-      double res[MAXR][R];
+      const T* __restrict__ wxr = fold_w ? gxw + (long long)wi * kpad : gxp + rk * kpad;
+      const T* __restrict__ wyr = fold_w ? gyw + (long long)wi * kpad : gyp + rk * kpad;
+      T res[MAXR][R];
 #pragma unroll
       for (int q = 0; q < MAXR; ++q) {
         const int ridx = q * 64 + lane;
 #pragma unroll
-        for (int r = 0; r < R; ++r) res[q][r] = 0.0;
+        for (int r = 0; r < R; ++r) res[q][r] = 0;
         if (q * 64 < nlr && ridx < nlr) {
           const int rr = s_rowlist[ridx];
-          const double* row = tile + rr * P + wv * R;
-          double win[R];
+          const T* row = tile + rr * P + wv * R;
+          T win[R];
 #pragma unroll
           for (int r = 0; r < R - 1; ++r) win[r] = row[r];
           for (int u0 = 0; u0 < kpad; u0 += R) {
 #pragma unroll
             for (int qq = 0; qq < R; ++qq) {
               win[(qq + R - 1) % R] = row[u0 + qq + R - 1];
-              const double wgt = wxr[u0 + qq];
+              const T wgt = wxr[u0 + qq];
 #pragma unroll
               for (int r = 0; r < R; ++r)
                 res[q][r] = fma(wgt, win[(r + qq) % R], res[q][r]);
@@ -1445,7 +1493,7 @@ k_conv_chi2(FitK g, const double* __restrict__ iunif,
           const unsigned long long mw = q == 0 ? m0 : q == 1 ? m1 : q == 2 ? m2 : m3;
           if (!((mw >> lane) & 1ull)) {
 #pragma unroll
-            for (int r = 0; r < R; ++r) tmp[rr * P2 + wv * R + r] = 0.0;
+            for (int r = 0; r < R; ++r) tmp[rr * P2 + wv * R + r] = 0;
           }
         }
       }
@@ -1462,7 +1510,7 @@ k_conv_chi2(FitK g, const double* __restrict__ iunif,
       STAMP(4);
 
       if (wv < TY / R) {
-        const double* col = tmp + (wv * R) * P2 + lane;
+        const T* col = tmp + (wv * R) * P2 + lane;
         for (int u0 = 0; u0 < kpad; u0 += R) {
           // rows wv*R+u0 .. +2R-2 feed this tap block: skip it if none holds emission
           const int ra = wv * R + u0;
@@ -1474,12 +1522,12 @@ k_conv_chi2(FitK g, const double* __restrict__ iunif,
             bits = (lo >> sh) | (sh ? (hi << (64 - sh)) : 0ull);
           }
           if (!(bits & ((1ull << (2 * R - 1)) - 1ull))) continue;
-          double win[2 * R - 1];
+          T win[2 * R - 1];
 #pragma unroll
           for (int r = 0; r < 2 * R - 1; ++r) win[r] = col[(u0 + r) * P2];
 #pragma unroll
           for (int qq = 0; qq < R; ++qq) {
-            const double wgt = wyr[u0 + qq];
+            const T wgt = wyr[u0 + qq];
 #pragma unroll
             for (int r = 0; r < R; ++r) acc[r] = fma(wgt, win[r + qq], acc[r]);
           }
@@ -1494,7 +1542,7 @@ k_conv_chi2(FitK g, const double* __restrict__ iunif,
       if (wv < TY / R) {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-          const double a = (pixx >= 0 && ((fvalid >> r) & 1u)) ? acc[r] : 0.0;
+          const double a = (pixx >= 0 && ((fvalid >> r) & 1u)) ? (double)acc[r] : 0.0;
           gf = fma(a, fdv[r], gf);
           ff = fma(a, a, ff);
         }
@@ -1517,7 +1565,7 @@ k_conv_chi2(FitK g, const double* __restrict__ iunif,
       const bool xown = i1 >= 0 && i1 < TX - 1;               // else owned by another window
       lds_barrier();                                        // column pass done reading LDS
       if (DIRECT) {
-        double* half = lds + TY * PC;                         // the odd tap columns' sums
+        T* half = lds + TY * PC;                         // the odd tap columns' sums
         if (tapset == 1) {
   #pragma unroll
           for (int r = 0; r < RB; ++r) half[(rb * RB + r) * PC + lane] = dacc[r];
@@ -1543,7 +1591,7 @@ k_conv_chi2(FitK g, const double* __restrict__ iunif,
           const int i0 = i0q[q];                              // wave-uniform
           if (xown && i0 >= 0 && i0 < TY - 1) {
             const double t0 = t0q[q];
-            const double* c = lds + i0 * PC + i1;
+            const T* c = lds + i0 * PC + i1;
             const double v00 = c[0], v01 = c[1], v10 = c[PC], v11 = c[PC + 1];
             const double val = v00 * (1 - t0) * (1 - t1) + v01 * (1 - t0) * t1 +
                                v10 * t0 * (1 - t1) + v11 * t0 * t1;
@@ -1561,9 +1609,9 @@ k_conv_chi2(FitK g, const double* __restrict__ iunif,
           const int i0 = celly[(long long)wi * g.ny + jy] - y0;
           if (i0 < 0 || i0 >= TY - 1) continue;
           const double t0 = fracy[(long long)wi * g.ny + jy];
-          const double* c = lds + i0 * PC + i1b;
-          const double val = c[0] * (1 - t0) * (1 - t1b) + c[1] * (1 - t0) * t1b +
-                             c[PC] * t0 * (1 - t1b) + c[PC + 1] * t0 * t1b;
+          const T* c = lds + i0 * PC + i1b;
+          const double val = (double)c[0] * (1 - t0) * (1 - t1b) + (double)c[1] * (1 - t0) * t1b +
+                             (double)c[PC] * t0 * (1 - t1b) + (double)c[PC + 1] * t0 * t1b;
           gf = fma(val, dat[(long long)jy * g.nx + ix2], gf);
           ff = fma(val, val, ff);
         }
@@ -1822,8 +1870,9 @@ k_count_flags(const unsigned char* __restrict__ flags, long long nflag,
   count_add(&cnt[5], groups);
 }
 
+template <typename T2>
 __global__ void __launch_bounds__(256)
-k_count_hits(FitK g, const WalkerK* __restrict__ wk, const double2* __restrict__ geom,
+k_count_hits(FitK g, const WalkerK* __restrict__ wk, const T2* __restrict__ geom,
              const unsigned* __restrict__ gflag, int nw, unsigned long long* __restrict__ cnt) {
   const long long slot = (long long)blockIdx.x * 256 + threadIdx.x;   // nslot is a multiple of 256
   unsigned long long hits = 0, wavehits = 0;
@@ -1833,7 +1882,7 @@ k_count_hits(FitK g, const WalkerK* __restrict__ wk, const double2* __restrict__
     const double hw = wk[wi].halfwidth, voff = wk[wi].voff;
     for (int s = 0; s < 4; ++s) {
       if (!((fm >> s) & 1u)) continue;                      // wave-uniform
-      const double o = geom[((long long)wi * 4 + s) * g.nslot + slot].x + voff;
+      const double o = (double)geom[((long long)wi * 4 + s) * g.nslot + slot].x + voff;
       for (int cix = 0; cix < nchunk; ++cix) {
         const double cmid = 0.5 * (g.ch_vmin[cix] + g.ch_vmax[cix]);
         const double hwc = hw + 0.5 * (g.ch_vmax[cix] - g.ch_vmin[cix]);
@@ -2324,6 +2373,13 @@ k_sum_chi2(FitK g, const double* __restrict__ partial, int nblk,
   }
 }
 
+// float Iunif -> double, for the parity taps and cubemodel at precision 1
+__global__ void k_widen(const float* __restrict__ in, double* __restrict__ out, long long n) {
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n;
+       e += (long long)gridDim.x * blockDim.x)
+    out[e] = (double)in[e];
+}
+
 __global__ void k_scale(double* __restrict__ cube, long long n,
                         const double* __restrict__ stats) {
   const double s = stats[2];
@@ -2354,11 +2410,11 @@ struct Scratch {
   int wgroup = 0;              // walkers per launch group
   WalkerK* wk = nullptr;
   double* params = nullptr;
-  double2* geom = nullptr;     // [walker][surface][sample] {vlos*sqrt(M), weight}
+  void* geom = nullptr;        // [walker][surface][sample] {vlos*sqrt(M), weight} as double2 or float2
   unsigned* gflag = nullptr;   // [walker][sample / 64] bit s: surface s of these 64 samples was stored
   float2* grange = nullptr;    // [walker][sample / 64] range of the stored vlos*sqrt(M) of these 64 samples
   uint2* items = nullptr;      // k_plan's list: (walker * tiles + tile, channel block) that can hold emission
-  double* iunif = nullptr;
+  void* iunif = nullptr;       // [walker][nv][nneed][nneed], double or float
   double* partial = nullptr;
   double* stats = nullptr;
   double* tk = nullptr;        // [walker][nvpad] scaled channel table (FitK::tk of a launch)
@@ -2375,6 +2431,8 @@ struct Scratch {
   int* tile_jy = nullptr;
   double* gxw = nullptr;       // [walker][kpad] folded row / column taps
   double* gyw = nullptr;
+  float* gxw32 = nullptr;      // the same in single precision (f32 only)
+  float* gyw32 = nullptr;
   // Calls that use this set are ordered: `done` is recorded behind the last
   // launch that touched it, and a call on another stream waits for it first.
   hipEvent_t done = nullptr;
@@ -2422,7 +2480,16 @@ struct slamhip_ctx {
   int separable = 0;
   int conv_mode = 0;
   int kpad = 0;
-  int sep_variant = 0;     // 0: <64,3>  1: <64,5>  2: <32,4>  -1: none fits
+  int sep_variant = 0;     // dense conv tile: 0: <64,3>  1: <64,5>  2: <32,4>  -1: none fits
+  int fz_variant = 0;      // fused kernel's tile (same ladder, sized for the arithmetic type)
+  int f32 = 0;             // profile accumulation, Iunif and beam passes in single precision (precision 1, 2)
+  int g32 = 0;             // geometry in single precision too (precision 2)
+  size_t item = 8;         // bytes of an Iunif / tile element
+  size_t gitem = 8;        // bytes of a geometry value
+  const float* gx32 = nullptr;   // single-precision copies of the beam taps (f32 only)
+  const float* gy32 = nullptr;
+  const float* ft32 = nullptr;
+  double* d_iunif64 = nullptr;   // f32: one walker's Iunif as double for the parity taps / cubemodel
   int nrank = 1;           // outer-product terms of the factorised beam (0: not factorised)
   int fz_rank = 1;         // what the fused kernel uses in conv mode 0: nrank, or 0 = direct taps
   size_t fz_lds_direct = 0;
@@ -2529,11 +2596,11 @@ size_t carve(const slamhip_ctx* c, size_t W, unsigned char* base, Scratch* s) {
   Scratch t;
   t.wk = reinterpret_cast<WalkerK*>(take(W * sizeof(WalkerK)));
   t.params = reinterpret_cast<double*>(take(W * NP * sizeof(double)));
-  t.geom = reinterpret_cast<double2*>(take(W * 4 * (size_t)k.nslot * sizeof(double2)));
+  t.geom = take(W * 4 * (size_t)k.nslot * 2 * c->gitem);
   t.gflag = reinterpret_cast<unsigned*>(take(W * (size_t)(k.nslot / 64) * sizeof(unsigned)));
   t.grange = reinterpret_cast<float2*>(take(W * (size_t)(k.nslot / 64) * sizeof(float2)));
   t.items = reinterpret_cast<uint2*>(take(W * (size_t)c->ftx * c->fty * (k.nvpad / CH) * sizeof(uint2)));
-  t.iunif = reinterpret_cast<double*>(take(W * k.nv * n * n * sizeof(double)));
+  t.iunif = take(W * k.nv * n * n * c->item);
   t.partial = reinterpret_cast<double*>(take(W * c->max_blocks * 3 * sizeof(double)));
   t.stats = reinterpret_cast<double*>(take(W * 6 * sizeof(double)));
   t.tk = reinterpret_cast<double*>(take(W * (size_t)k.nvpad * sizeof(double)));
@@ -2550,6 +2617,8 @@ size_t carve(const slamhip_ctx* c, size_t W, unsigned char* base, Scratch* s) {
   t.tile_jy = reinterpret_cast<int*>(take(W * c->fz_grid.y * 2 * sizeof(int)));
   t.gxw = reinterpret_cast<double*>(take(W * (size_t)c->kpad * sizeof(double)));
   t.gyw = reinterpret_cast<double*>(take(W * (size_t)c->kpad * sizeof(double)));
+  t.gxw32 = reinterpret_cast<float*>(take(W * (size_t)c->kpad * sizeof(float)));
+  t.gyw32 = reinterpret_cast<float*>(take(W * (size_t)c->kpad * sizeof(float)));
   if (s && base) {
     t.wgroup = s->wgroup; t.done = s->done; t.last = s->last; t.used = s->used;
     *s = t;
@@ -2734,19 +2803,22 @@ int run_model(slamhip_ctx* c, Scratch& S, const double* d_params, int nw, hipStr
   FitK k = c->k;
   k.tk = S.tk;
   if (dense)
-    HIP_TRY(c, hipMemsetAsync(S.iunif, 0, sizeof(double) * (size_t)nw * k.nv * k.nneed * k.nneed, st));
+    HIP_TRY(c, hipMemsetAsync(S.iunif, 0, c->item * (size_t)nw * k.nv * k.nneed * k.nneed, st));
   {
     Timed t_(c, KID_PREP, st);
     hipLaunchKernelGGL(k_prep, dim3(nw), dim3(256), 0, st, k, d_params, nw, S.wk,
                        S.cellx, S.fracx, S.celly, S.fracy, S.tile_ix,
                        S.tile_jy, (int)c->fz_grid.x, (int)c->fz_grid.y, c->fz_sx, c->fz_sy,
                        S.winflag, (int)(k.nv * c->fz_grid.x * c->fz_grid.y), S.livecount,
-                       S.gxw, S.gyw);
+                       S.gxw, S.gyw, c->f32 ? S.gxw32 : (float*)nullptr, c->f32 ? S.gyw32 : (float*)nullptr);
   }
   {
     Timed t_(c, KID_SURFACE, st);
     dim3 g1((unsigned)((k.nslot + 255) / 256), 1, (nw + SURF_WPT - 1) / SURF_WPT);
-    hipLaunchKernelGGL(k_surface, g1, dim3(256), 0, st, k, S.wk, S.geom, S.gflag, S.grange, nw);
+    if (c->g32)
+      hipLaunchKernelGGL(k_surface<float>, g1, dim3(256), 0, st, k, S.wk, (float2*)S.geom, S.gflag, S.grange, nw);
+    else
+      hipLaunchKernelGGL(k_surface<double>, g1, dim3(256), 0, st, k, S.wk, (double2*)S.geom, S.gflag, S.grange, nw);
   }
   {
     Timed t_(c, KID_PROFILE, st);
@@ -2758,14 +2830,14 @@ int run_model(slamhip_ctx* c, Scratch& S, const double* d_params, int nw, hipStr
                        S.grange, nw, ntile, S.items, nitems);
     // room for every triple (rounded up to whole groups of 8 for the XCD mapping)
     dim3 g2((unsigned)(((size_t)nw * ntile * (k.nvpad / CH) + 7) / 8 * 8), 1, 1);
-    if (k.fast_idx)
-      hipLaunchKernelGGL(k_profile<true>, g2, dim3(256), 0, st, k, S.wk, S.geom, S.gflag,
-                         S.iunif, S.flags, c->ftx, c->fty, S.winflag, (int)c->fz_grid.x, (int)c->fz_grid.y,
-                         c->fz_sx, c->fz_sy, S.items, nitems);
-    else
-      hipLaunchKernelGGL(k_profile<false>, g2, dim3(256), 0, st, k, S.wk, S.geom, S.gflag,
-                         S.iunif, S.flags, c->ftx, c->fty, S.winflag, (int)c->fz_grid.x, (int)c->fz_grid.y,
-                         c->fz_sx, c->fz_sy, S.items, nitems);
+#define SLAM_PROFILE(FAST_, T_, TG_, T2_)                                                         \
+    hipLaunchKernelGGL((k_profile<FAST_, T_, TG_>), g2, dim3(256), 0, st, k, S.wk, (const T2_*)S.geom, \
+                       S.gflag, (T_*)S.iunif, S.flags, c->ftx, c->fty, S.winflag, (int)c->fz_grid.x,  \
+                       (int)c->fz_grid.y, c->fz_sx, c->fz_sy, S.items, nitems)
+    if (c->g32)      { if (k.fast_idx) SLAM_PROFILE(true, float, float, float2); else SLAM_PROFILE(false, float, float, float2); }
+    else if (c->f32) { if (k.fast_idx) SLAM_PROFILE(true, float, double, double2); else SLAM_PROFILE(false, float, double, double2); }
+    else             { if (k.fast_idx) SLAM_PROFILE(true, double, double, double2); else SLAM_PROFILE(false, double, double, double2); }
+#undef SLAM_PROFILE
   }
   HIP_TRY(c, hipGetLastError());
   return SLAMHIP_OK;
@@ -2792,7 +2864,7 @@ int run_group_mom0(slamhip_ctx* c, Scratch& S, const double* d_params, int nw, d
     if (flagged)
       HIP_TRY(c, hipMemsetAsync(c->d_rowflag, 0, (size_t)nw * k.nv * k.ny * nseg, st));
     hipLaunchKernelGGL(k_regrid_mom0, dim3(nseg, (k.ny + 3) / 4, nw), dim3(256), 0, st, k,
-                       S.cellx, S.fracx, S.celly, S.fracy, S.iunif, S.flags,
+                       S.cellx, S.fracx, S.celly, S.fracy, (const double*)S.iunif, S.flags,
                        c->d_krange, c->ftx, c->fty, c->d_obs, flagged ? c->d_obflag : (unsigned char*)nullptr,
                        c->ob_ty ? c->ob_ty : 1, (int)c->ob_grid.x, c->ob_nty,
                        flagged ? c->d_rowflag : (unsigned char*)nullptr);
@@ -2859,6 +2931,42 @@ int run_group_mom0(slamhip_ctx* c, Scratch& S, const double* d_params, int nw, d
   return SLAMHIP_OK;
 }
 
+// The fused kernel's instance for the context's tile variant, tap form and
+// arithmetic type T (its address for hipFuncSetAttribute, or a launch).
+template <typename T>
+const void* fused_instance(int variant, bool direct, bool fixed) {
+  if (!direct)
+    return variant == 0 ? (const void*)k_conv_chi2<64, 2, false, 0, T>
+         : variant == 1 ? (const void*)k_conv_chi2<64, 3, false, 0, T>
+                        : (const void*)k_conv_chi2<32, 2, false, 0, T>;
+  if (fixed) return (const void*)k_conv_chi2<64, 2, true, DIRECT_PITCH, T>;
+  return variant == 0 ? (const void*)k_conv_chi2<64, 2, true, 0, T>
+       : variant == 1 ? (const void*)k_conv_chi2<64, 3, true, 0, T>
+                      : (const void*)k_conv_chi2<32, 2, true, 0, T>;
+}
+
+template <typename T>
+void launch_fused(slamhip_ctx* c, Scratch& S, int fz_rank, hipStream_t st, const T* gx, const T* gy,
+                  const T* ft, const T* gxw, const T* gyw) {
+  dim3 gz(fz_rank ? c->persist_blocks : c->persist_direct, 1, 1);
+  const size_t fz_lds = fz_rank ? c->fz_lds : c->fz_lds_direct;
+#define SLAM_FUSED(TY_, MR_, DIR_, PITCH_)                                                        \
+  hipLaunchKernelGGL((k_conv_chi2<TY_, MR_, DIR_, PITCH_, T>), gz, dim3(CV_NT), fz_lds, st, c->k, \
+                     (const T*)S.iunif, S.cellx, S.fracx, S.celly, S.fracy, S.livelist,           \
+                     S.livecount, (int)c->fz_grid.x, (int)c->fz_grid.y, S.partial, c->kpad,       \
+                     fz_rank, gx, gy, ft, gxw, gyw)
+  switch (c->fz_variant) {
+    case 0:
+      if (fz_rank) SLAM_FUSED(64, 2, false, 0);
+      else if (c->direct_fixed) SLAM_FUSED(64, 2, true, DIRECT_PITCH);
+      else SLAM_FUSED(64, 2, true, 0);
+      break;
+    case 1: if (fz_rank) SLAM_FUSED(64, 3, false, 0); else SLAM_FUSED(64, 3, true, 0); break;
+    default: if (fz_rank) SLAM_FUSED(32, 2, false, 0); else SLAM_FUSED(32, 2, true, 0); break;
+  }
+#undef SLAM_FUSED
+}
+
 int run_group(slamhip_ctx* c, Scratch& S, const double* d_params, int nw, double* d_chi2,
               hipStream_t st) {
   if (c->k.mom0decon) return run_group_mom0(c, S, d_params, nw, d_chi2, nullptr, true, st);
@@ -2878,29 +2986,10 @@ int run_group(slamhip_ctx* c, Scratch& S, const double* d_params, int nw, double
     }
     {
       Timed t_(c, KID_CONV, st);
-      dim3 gz(fz_rank ? c->persist_blocks : c->persist_direct, 1, 1);
-      const size_t fz_lds = fz_rank ? c->fz_lds : c->fz_lds_direct;
-#define SLAM_FUSED(TY_, MR_, DIR_)                                                        \
-      hipLaunchKernelGGL((k_conv_chi2<TY_, MR_, DIR_>), gz, dim3(CV_NT), fz_lds, st, c->k, \
-                         S.iunif, S.cellx, S.fracx, S.celly, S.fracy,       \
-                         S.livelist, S.livecount, (int)c->fz_grid.x, (int)c->fz_grid.y, \
-                         S.partial, c->kpad, fz_rank, c->k.gx_pad, c->k.gy_pad, c->k.beam_ft,        \
-                         S.gxw, S.gyw)
-      switch (c->sep_variant) {
-        case 0:
-          if (fz_rank) SLAM_FUSED(64, 2, false);
-          else if (c->direct_fixed)
-            hipLaunchKernelGGL((k_conv_chi2<64, 2, true, DIRECT_PITCH>), gz, dim3(CV_NT), fz_lds, st, c->k,
-                               S.iunif, S.cellx, S.fracx, S.celly, S.fracy,
-                               S.livelist, S.livecount, (int)c->fz_grid.x, (int)c->fz_grid.y,
-                               S.partial, c->kpad, fz_rank, c->k.gx_pad, c->k.gy_pad, c->k.beam_ft,
-                               S.gxw, S.gyw);
-          else SLAM_FUSED(64, 2, true);
-          break;
-        case 1: if (fz_rank) SLAM_FUSED(64, 3, false); else SLAM_FUSED(64, 3, true); break;
-        default: if (fz_rank) SLAM_FUSED(32, 2, false); else SLAM_FUSED(32, 2, true); break;
-      }
-#undef SLAM_FUSED
+      if (c->f32)
+        launch_fused<float>(c, S, fz_rank, st, c->gx32, c->gy32, c->ft32, S.gxw32, S.gyw32);
+      else
+        launch_fused<double>(c, S, fz_rank, st, c->k.gx_pad, c->k.gy_pad, c->k.beam_ft, S.gxw, S.gyw);
     }
     {
       Timed t_(c, KID_FINALIZE, st);
@@ -2913,7 +3002,7 @@ int run_group(slamhip_ctx* c, Scratch& S, const double* d_params, int nw, double
   }
   if (nw > c->iconv_walkers)                  // group_cap() keeps dense groups within the buffer
     return fail(c, SLAMHIP_ERR_STATE, "dense conv buffer holds %d walkers, group has %d", c->iconv_walkers, nw);
-  rc = run_conv(c, S.iunif, c->d_iconv, nw * c->k.nv, st);
+  rc = run_conv(c, (const double*)S.iunif, c->d_iconv, nw * c->k.nv, st);
   if (rc) return rc;
   {
     Timed t_(c, KID_REGRID, st);
@@ -2941,7 +3030,7 @@ int slamhip_device_count(void) {
   return n;
 }
 
-const char* slamhip_version(void) { return "slamhip 0.1 (gfx950, fp64)"; }
+const char* slamhip_version(void) { return "slamhip 0.2 (gfx950, fp64 / fp32)"; }
 
 const char* slamhip_last_error(slamhip_ctx* ctx) {
   return ctx ? ctx->err.c_str() : "null context";
@@ -2955,6 +3044,14 @@ int slamhip_create(const slamhip_desc* d, slamhip_ctx** out) {
   if (int bad = check_desc(d))
     return fail(c, SLAMHIP_ERR_ARG, "invalid descriptor (check %d)", bad);
   HIP_TRY(c, hipGetDevice(&c->device));
+  if (d->precision < 0 || d->precision > 2)
+    return fail(c, SLAMHIP_ERR_ARG, "precision %d: 0 (double), 1 (float) or 2 (float, geometry too)", d->precision);
+  if (d->precision != 0 && d->mom0decon)
+    return fail(c, SLAMHIP_ERR_ARG, "precision 1 / 2 (float) cover scaling 'uniform' only");
+  c->f32 = d->precision >= 1;
+  c->g32 = d->precision == 2;
+  c->item = c->f32 ? sizeof(float) : sizeof(double);
+  c->gitem = c->g32 ? sizeof(float) : sizeof(double);
   FitK& k = c->k;
   k.nv = d->nv; k.ny = d->ny; k.nx = d->nx; k.nlayer = d->nlayer; k.npix = d->npix;
   k.nq1 = d->nq1; k.nq3 = d->nq3; k.ineed0 = d->ineed0; k.ineed1 = d->ineed1;
@@ -3074,14 +3171,19 @@ int slamhip_create(const slamhip_desc* d, slamhip_ctx** out) {
       c->nrank = 0;                  // not factorisable cheaply: direct 2-D taps only
     }
   }
-  c->sep_variant = -1;
-  if (fz_tile_bytes(64, c->kpad) <= 78 * 1024 && (64 + c->kpad - 1) * (CONV_TX / CONV_R) <= 3 * 256) {
-    c->sep_variant = 0; c->sep_lds = sep_lds_bytes(64, c->kpad);
-  } else if (fz_tile_bytes(64, c->kpad) + 2 * c->kpad * sizeof(double) <= 156 * 1024 && (64 + c->kpad - 1) * (CONV_TX / CONV_R) <= 5 * 256) {
-    c->sep_variant = 1; c->sep_lds = sep_lds_bytes(64, c->kpad);
-  } else if (fz_tile_bytes(32, c->kpad) + 2 * c->kpad * sizeof(double) <= 156 * 1024 && (32 + c->kpad - 1) * (CONV_TX / CONV_R) <= 4 * 256) {
-    c->sep_variant = 2; c->sep_lds = sep_lds_bytes(32, c->kpad);
-  }
+  // LDS tile ladder: 64-row windows with two workgroups per CU, 64-row windows with one,
+  // 32-row windows; the fused kernel's tile is sized in its arithmetic type, the dense
+  // (parity tap) kernels always work in double.
+  auto pick_variant = [&](size_t item) {
+    auto tile = [&](int ty) { return fz_tile_bytes(ty, c->kpad) / sizeof(double) * item; };
+    if (tile(64) <= 78 * 1024 && (64 + c->kpad - 1) * (CONV_TX / CONV_R) <= 3 * 256) return 0;
+    if (tile(64) + 2 * c->kpad * item <= 156 * 1024 && (64 + c->kpad - 1) * (CONV_TX / CONV_R) <= 5 * 256) return 1;
+    if (tile(32) + 2 * c->kpad * item <= 156 * 1024 && (32 + c->kpad - 1) * (CONV_TX / CONV_R) <= 4 * 256) return 2;
+    return -1;
+  };
+  c->sep_variant = pick_variant(sizeof(double));
+  c->fz_variant = pick_variant(c->item);
+  if (c->sep_variant >= 0) c->sep_lds = sep_lds_bytes(c->sep_variant == 2 ? 32 : 64, c->kpad);
   c->c2d_lds = (size_t)(C2_TY + K - 1) * ((C2_TX + K - 1) | 1) * sizeof(double);
   if (c->sep_lds > 48 * 1024) {   // opt in to large dynamic LDS for the chosen variant only
     const void* fn = c->sep_variant == 0 ? (const void*)k_conv_sep<64, 3>
@@ -3089,12 +3191,12 @@ int slamhip_create(const slamhip_desc* d, slamhip_ctx** out) {
                                          : (const void*)k_conv_sep<32, 4>;
     HIP_TRY(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->sep_lds));
   }
-  const size_t fz_tile = c->sep_variant < 0 ? 0 : fz_tile_bytes(c->sep_variant == 2 ? 32 : 64, c->kpad);
-  c->fz_lds = fz_tile + 2 * (size_t)std::max(c->nrank, 1) * c->kpad * sizeof(double);
-  if (c->nrank > 1 && c->sep_variant >= 0) {
+  const size_t fz_ty = c->fz_variant == 2 ? 32 : 64;
+  const size_t fz_tile = c->fz_variant < 0 ? 0 : fz_tile_bytes((int)fz_ty, c->kpad) / sizeof(double) * c->item;
+  c->fz_lds = fz_tile + 2 * (size_t)std::max(c->nrank, 1) * c->kpad * c->item;
+  if (c->nrank > 1 && c->fz_variant >= 0) {
     // several beam terms: the row-pass intermediate cannot overlay the tile
-    const int ty = c->sep_variant == 2 ? 32 : 64;
-    c->fz_lds += (size_t)(ty + c->kpad - 1) * (CONV_TX + 1) * sizeof(double);
+    c->fz_lds += (fz_ty + c->kpad - 1) * (CONV_TX + 1) * c->item;
     if (c->fz_lds > 156 * 1024) c->nrank = 0;
   }
   // The fused kernel either applies the factorised beam or, when that takes
@@ -3102,32 +3204,27 @@ int slamhip_create(const slamhip_desc* d, slamhip_ctx** out) {
   // multiply-adds than the K x K taps themselves, plus an intermediate),
   // direct taps on the staged tile.
   {
-    const size_t ty = c->sep_variant == 2 ? 32 : 64;
     // the common case (64-row windows, K <= 32) runs with the tile pitch fixed at DIRECT_PITCH
-    c->direct_fixed = c->sep_variant == 0 && c->kpad <= 32;
-    const size_t tile = c->direct_fixed ? ((ty + c->kpad - 1) * DIRECT_PITCH + 2) * sizeof(double) : fz_tile;
-    c->fz_lds_direct = std::max(tile, 2 * ty * (CONV_TX + 1) * sizeof(double));
+    c->direct_fixed = c->fz_variant == 0 && c->kpad <= 32;
+    const size_t tile = c->direct_fixed ? ((fz_ty + c->kpad - 1) * DIRECT_PITCH + 2) * c->item : fz_tile;
+    c->fz_lds_direct = std::max(tile, 2 * fz_ty * (CONV_TX + 1) * c->item);
   }
-  const bool direct_ok = c->sep_variant >= 0 && c->fz_lds_direct <= 156 * 1024;   // taps + tile fit the LDS
+  const bool direct_ok = c->fz_variant >= 0 && c->fz_lds_direct <= 156 * 1024;   // taps + tile fit the LDS
   c->fz_rank = (c->nrank >= 1 && (c->nrank < DIRECT_MIN_RANK || !direct_ok)) ? c->nrank : 0;
-  if (c->sep_variant >= 0) {
-    const void* fz = c->sep_variant == 0 ? (const void*)k_conv_chi2<64, 2, false>
-                   : c->sep_variant == 1 ? (const void*)k_conv_chi2<64, 3, false>
-                                         : (const void*)k_conv_chi2<32, 2, false>;
-    const void* fd = c->sep_variant == 0 ? (const void*)k_conv_chi2<64, 2, true>
-                   : c->sep_variant == 1 ? (const void*)k_conv_chi2<64, 3, true>
-                                         : (const void*)k_conv_chi2<32, 2, true>;
+  if (c->fz_variant >= 0) {
+    const void* fz = c->f32 ? fused_instance<float>(c->fz_variant, false, false)
+                            : fused_instance<double>(c->fz_variant, false, false);
+    const void* fd = c->f32 ? fused_instance<float>(c->fz_variant, true, c->direct_fixed)
+                            : fused_instance<double>(c->fz_variant, true, c->direct_fixed);
     if (c->nrank >= 1)
       HIP_TRY(c, hipFuncSetAttribute(fz, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->fz_lds));
-    if (c->direct_fixed) fd = (const void*)k_conv_chi2<64, 2, true, DIRECT_PITCH>;
     if (direct_ok)
       HIP_TRY(c, hipFuncSetAttribute(fd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->fz_lds_direct));
   }
-  c->fused = c->sep_variant >= 0 && (c->fz_rank >= 1 || direct_ok);
+  c->fused = c->fz_variant >= 0 && (c->fz_rank >= 1 || direct_ok);
   {
-    const int ty = c->sep_variant == 2 ? 32 : 64;
     c->fz_sx = CONV_TX - 1;
-    c->fz_sy = ty - 1;
+    c->fz_sy = (int)fz_ty - 1;
     c->fz_grid = dim3((n - 1 + c->fz_sx - 1) / c->fz_sx, (n - 1 + c->fz_sy - 1) / c->fz_sy, k.nv);
   }
   if (c->c2d_lds > 48 * 1024 && c->c2d_lds <= 160 * 1024) {
@@ -3162,6 +3259,12 @@ int slamhip_create(const slamhip_desc* d, slamhip_ctx** out) {
       for (int a = 0; a < K; ++a)
         ft[(size_t)b * c->kpad + a] = d->gaussbeam[(size_t)(K - 1 - a) * K + (K - 1 - b)];
     if ((rc = dev_upload(c, &k.beam_ft, ft.data(), ft.size()))) return rc;
+    if (c->f32) {
+      std::vector<float> f32v(ft.begin(), ft.end()), gxf(gx.begin(), gx.end()), gyf(gy.begin(), gy.end());
+      if ((rc = dev_upload(c, &c->ft32, f32v.data(), f32v.size()))) return rc;
+      if ((rc = dev_upload(c, &c->gx32, gxf.data(), gxf.size()))) return rc;
+      if ((rc = dev_upload(c, &c->gy32, gyf.data(), gyf.size()))) return rc;
+    }
   }
   if ((rc = dev_upload(c, &k.leaf, leaves.data(), leaves.size()))) return rc;
   if ((rc = dev_upload(c, &k.tile_goff, tile_goff.data(), tile_goff.size()))) return rc;
@@ -3231,7 +3334,7 @@ int slamhip_create(const slamhip_desc* d, slamhip_ctx** out) {
   if (d->mom0decon && (rc = dev_alloc(c, &c->d_rowflag, W * (size_t)k.nv * k.ny * nseg))) return rc;
   {
     // a conv window must not span more occupancy bytes than its LDS table holds
-    const int ty = c->sep_variant == 2 ? 32 : 64;
+    const int ty = c->fz_variant == 2 ? 32 : 64;
     const int spanx = (CONV_TX + K - 2) / PT_X + 2, spany = (ty + K - 2) / PT_Y + 2;
     if (c->fused && (spanx * spany > FLAG_MAX || spanx > 255 || spany > 255)) c->fused = 0;   // descriptor ids pack (fy, fx) in 8 bits each
     if ((int)(c->fz_grid.x + c->fz_grid.y) > PREP_TILES) c->fused = 0;
@@ -3352,6 +3455,8 @@ int slamhip_beam_rank(slamhip_ctx* c) {
 
 int slamhip_set_conv_mode(slamhip_ctx* c, int mode) {
   if (!c || mode < 0 || mode > 2) return SLAMHIP_ERR_ARG;
+  if (mode == 1 && c->f32)
+    return fail(c, SLAMHIP_ERR_ARG, "conv mode 1 (dense, double) is not available at precision 1 (float)");
   if (mode == 1 && !c->k.mom0decon) {
     // the dense path keeps whole convolved cubes: room for a few walkers per
     // launch group is made here, so that the batch entry points never allocate
@@ -3491,13 +3596,30 @@ static int single_finish(slamhip_ctx* c, hipError_t e, const char* what) {
   return SLAMHIP_OK;
 }
 
+// One walker's Iunif as double on the context's stream: the scratch itself, or
+// (precision 1) its widened copy in a buffer kept from the first such call.
+static int iunif_as_double(slamhip_ctx* c, const double** out) {
+  Scratch& S = c->own;
+  if (!c->f32) { *out = static_cast<const double*>(S.iunif); return SLAMHIP_OK; }
+  const size_t n1 = (size_t)c->k.nv * c->k.nneed * c->k.nneed;
+  int rc;
+  if (!c->d_iunif64 && (rc = dev_alloc(c, &c->d_iunif64, n1))) return rc;
+  hipLaunchKernelGGL(k_widen, dim3(1024), dim3(256), 0, c->stream, static_cast<const float*>(S.iunif),
+                     c->d_iunif64, (long long)n1);
+  HIP_TRY(c, hipGetLastError());
+  *out = c->d_iunif64;
+  return SLAMHIP_OK;
+}
+
 int slamhip_iunif(slamhip_ctx* c, const double* params, double* out) {
   int rc = single_prepare(c, params);
   if (rc) return rc;
   Scratch& S = c->own;
   if ((rc = run_model(c, S, S.params, 1, c->stream, true))) return rc;
   const size_t nb = (size_t)c->k.nv * c->k.nneed * c->k.nneed * sizeof(double);
-  return single_finish(c, hipMemcpyAsync(out, S.iunif, nb, hipMemcpyDeviceToHost, c->stream), "iunif");
+  const double* iu = nullptr;
+  if ((rc = iunif_as_double(c, &iu))) return rc;
+  return single_finish(c, hipMemcpyAsync(out, iu, nb, hipMemcpyDeviceToHost, c->stream), "iunif");
 }
 
 int slamhip_iconv(slamhip_ctx* c, const double* params, double* out) {
@@ -3505,7 +3627,9 @@ int slamhip_iconv(slamhip_ctx* c, const double* params, double* out) {
   if (rc) return rc;
   Scratch& S = c->own;
   if ((rc = run_model(c, S, S.params, 1, c->stream, true))) return rc;
-  if ((rc = run_conv(c, S.iunif, c->d_iconv, c->k.nv, c->stream))) return rc;
+  const double* iu = nullptr;
+  if ((rc = iunif_as_double(c, &iu))) return rc;
+  if ((rc = run_conv(c, iu, c->d_iconv, c->k.nv, c->stream))) return rc;
   const size_t nb = (size_t)c->k.nv * c->k.nneed * c->k.nneed * sizeof(double);
   return single_finish(c, hipMemcpyAsync(out, c->d_iconv, nb, hipMemcpyDeviceToHost, c->stream), "iconv");
 }
@@ -3534,10 +3658,12 @@ int slamhip_cubemodel(slamhip_ctx* c, const double* params, int convolving,
     return single_finish(c, e, "cubemodel");
   }
   if ((rc = run_model(c, S, S.params, 1, c->stream, true))) return rc;
+  const double* iu = nullptr;
+  if ((rc = iunif_as_double(c, &iu))) return rc;
   if (convolving) {
-    if ((rc = run_conv(c, S.iunif, c->d_iconv, k.nv, c->stream))) return rc;
+    if ((rc = run_conv(c, iu, c->d_iconv, k.nv, c->stream))) return rc;
   } else {
-    hipLaunchKernelGGL(k_peak_unity, dim3(k.nv), dim3(256), 0, c->stream, k, S.iunif, c->d_iconv,
+    hipLaunchKernelGGL(k_peak_unity, dim3(k.nv), dim3(256), 0, c->stream, k, iu, c->d_iconv,
                        (long long)k.nneed * k.nneed);
   }
   hipLaunchKernelGGL((k_regrid<true>), c->rg_grid, dim3(RED_THREADS), 0, c->stream, k,
@@ -3562,7 +3688,8 @@ static int prep_only(slamhip_ctx* c, WalkerK* hw) {
   hipLaunchKernelGGL(k_prep, dim3(1), dim3(256), 0, c->stream, k, S.params, 1, S.wk,
                      S.cellx, S.fracx, S.celly, S.fracy, S.tile_ix,
                      S.tile_jy, (int)c->fz_grid.x, (int)c->fz_grid.y, c->fz_sx, c->fz_sy,
-                     (unsigned char*)nullptr, 0, (int*)nullptr, (double*)nullptr, (double*)nullptr);
+                     (unsigned char*)nullptr, 0, (int*)nullptr, (double*)nullptr, (double*)nullptr,
+                     (float*)nullptr, (float*)nullptr);
   HIP_TRY(c, hipGetLastError());
   HIP_TRY(c, hipMemcpyAsync(hw, S.wk, sizeof *hw, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -3622,8 +3749,12 @@ int slamhip_group_counts(slamhip_ctx* c, int nw, int64_t* out) {
                      c->fz_sy + 1, c->kpad, cnt);
   hipLaunchKernelGGL(k_count_flags, dim3(1024), dim3(256), 0, c->stream, S.flags,
                      (long long)nw * k.nv * c->ftx * c->fty, S.gflag, (long long)nw * (k.nslot >> 6), cnt);
-  hipLaunchKernelGGL(k_count_hits, dim3((unsigned)(k.nslot / 256)), dim3(256), 0, c->stream, k, S.wk,
-                     S.geom, S.gflag, nw, cnt);
+  if (c->g32)
+    hipLaunchKernelGGL(k_count_hits<float2>, dim3((unsigned)(k.nslot / 256)), dim3(256), 0, c->stream, k, S.wk,
+                       (const float2*)S.geom, S.gflag, nw, cnt);
+  else
+    hipLaunchKernelGGL(k_count_hits<double2>, dim3((unsigned)(k.nslot / 256)), dim3(256), 0, c->stream, k, S.wk,
+                       (const double2*)S.geom, S.gflag, nw, cnt);
   HIP_TRY(c, hipGetLastError());
   unsigned long long h[8];
   hipError_t e = hipMemcpyAsync(h, cnt, sizeof h, hipMemcpyDeviceToHost, c->stream);

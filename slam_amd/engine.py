@@ -28,7 +28,7 @@ class HipLikelihood:
     the x-flipped kernel).
     """
 
-    def __init__(self, setup, max_scratch_bytes=0):
+    def __init__(self, setup, max_scratch_bytes=0, precision='f64'):
         self._lib = _lib.load()
         self._ctx = C.c_void_p()
         if self._lib.slamhip_device_count() < 1:
@@ -73,6 +73,11 @@ class HipLikelihood:
             max_scratch_bytes=int(max_scratch_bytes))
         if self.mom0:
             d.mom0decon = as_dp(keep['mom0decon'])
+        levels = {'f64': 0, 'f32': 1, 'f32g': 2}
+        if precision not in levels:
+            raise ValueError(f'precision must be one of {sorted(levels)}')
+        self.precision = precision
+        d.precision = levels[precision]
         rc = self._lib.slamhip_create(C.byref(d), C.byref(self._ctx))
         if rc != 0:
             msg = self._errmsg()
