@@ -1,6 +1,6 @@
 """Drop-in `ChannelFit` whose likelihood runs on the MI355X.
 
-Same constructor, `makegrid`, `fitting`, `cubemodel`, `modeltofits`, `plotmom`
+Same constructor, `makegrid`, `fitting`, `cubemodel`, `modeltofits`
 signatures and result attributes (`popt/plow/pmid/phigh` dicts, `chi2r`,
 `<filename>.popt.txt`) as the reference class
 (jinshisai/SLAM `channelfit/_channelfit.py:212-792`).  What changes:
@@ -81,6 +81,12 @@ class ChannelFit(ReadFits):
         self.bmaj, self.bmin, self.bpa = float(bmaj), float(bmin), float(bpa)
         self.sigma = float(sigma)
         self.offpix = (0, 0, 0)
+        # a header for modeltofits: linear axes in the units the arrays are in
+        self.header = {'NAXIS': 3, 'BUNIT': 'Jy/beam', 'BMAJ': self.bmaj, 'BMIN': self.bmin,
+                       'BPA': self.bpa}
+        for ax, (c, unit) in enumerate(((self.x, 'au'), (self.y, 'au'), (self.v, 'km/s')), 1):
+            self.header.update({f'NAXIS{ax}': len(c), f'CRPIX{ax}': 1.0, f'CRVAL{ax}': float(c[0]),
+                                f'CDELT{ax}': float(c[1] - c[0]), f'CUNIT{ax}': unit})
 
     def makegrid(self, cubefits: str | None = None,
                  pa: float = 0, incl: float = 90, dist: float = 1,
@@ -407,44 +413,3 @@ class ChannelFit(ReadFits):
         write_cube(f'{filehead}.residual.fits', self.data - model, h)
         write_cube(f'{filehead}.beforeconvolving.fits',
                    self._full_velocity_cube(m0), h)
-
-    def plotmom(self, mode: str, filename: str = 'mom01.png', **kwargs):
-        """Moment 0/1 figure of the observation, model or residual (:720-762)."""
-        import matplotlib
-        matplotlib.use('Agg', force=False)
-        import matplotlib.pyplot as plt
-        from matplotlib.patches import Ellipse
-        if 'mod' in mode or 'res' in mode or 'clean' in mode:
-            if kwargs != {}:
-                self.popt = kwargs
-            m = makemom01(self.cubemodel(**self.popt), self.v_valid, self.sigma)
-        if 'obs' in mode:
-            mom0, mom1, label = self.mom0, self.mom1, 'Obs.'
-        elif 'mod' in mode:
-            mom0, mom1, label = m['mom0'], m['mom1'], 'Model'
-        elif 'res' in mode:
-            mom0, mom1 = self.mom0 - m['mom0'], self.mom1 - m['mom1']
-            label = r'Obs. $-$ model'
-        levels = (3 if 'res' in mode else 6) * self.sigma_mom0
-        levels = np.arange(1, 20) * levels
-        levels = np.sort(np.r_[-levels, levels])
-        fig = plt.figure()
-        ax = fig.add_subplot(1, 1, 1)
-        vplot = (np.nanpercentile(self.mom1, 99) - np.nanpercentile(self.mom1, 1)) / 2.
-        im = ax.pcolormesh(self.x, self.y, mom1, cmap='jet', shading='nearest',
-                           vmin=-vplot, vmax=vplot)
-        fig.colorbar(im, ax=ax, label=label + r' mom1 (km s$^{-1}$)')
-        ax.contour(self.x, self.y, mom0, colors='gray', levels=levels)
-        r = np.linspace(-1, 1, 3) * self.x.max() * 1.42
-        ax.plot(r * self.sinpa, r * self.cospa, 'k:')
-        ax.plot(r * self.cospa, -r * self.sinpa, 'k:')
-        bpos = np.max(self.x) - 0.7 * self.bmaj
-        ax.add_patch(Ellipse((bpos, -bpos), width=self.bmin, height=self.bmaj,
-                             angle=self.bpa * np.sign(self.dx), facecolor='gray'))
-        ax.set_xlabel('R.A. offset (au)')
-        ax.set_ylabel('Dec. offset (au)')
-        ax.set_xlim(self.x.max() * 1.01, self.x.min() * 1.01)
-        ax.set_ylim(self.y.min() * 1.01, self.y.max() * 1.01)
-        ax.set_aspect(1)
-        fig.savefig(filename)
-        plt.close()

@@ -1,8 +1,10 @@
 """PVFitting: drop-in for the reference's `pvfitting.PVFitting`
 (pvfitting/_pvfitting.py) whose model evaluations run on the MI355X.
 
-Same methods and arguments (put_PV, check_modelgrid, fit_mockpvd, read_fitres,
-plot_pvds, modeltofits); the sampler receives a vectorised log-probability
+Same methods and arguments for the fitting path (put_PV, check_modelgrid,
+fit_mockpvd, read_fitres; `plot`, `show`, `title`, `log` are accepted and not acted
+on: figures and the PV FITS writer are out of this package's scope, `makemodel`
+returns the model diagrams to draw or write); the sampler receives a vectorised log-probability
 (p[nw, ndim] -> lnp[nw]) that calls libslampv.so once per ensemble half.
 """
 from __future__ import annotations
@@ -16,11 +18,14 @@ _ILOG = np.array([0, 1, 2, 3, 4], dtype=int)        # _pvfitting.py:162
 
 
 def getquad(m):
-    """Sign of the PV diagram's dominant quadrant pair (_pvfitting.py:462-469)."""
-    nv, nx = np.shape(m)
-    q = np.sum(m[:nv // 2, :nx // 2]) + np.sum(m[nv // 2:, nx // 2:]) \
-        - np.sum(m[nv // 2:, :nx // 2]) - np.sum(m[:nv // 2, nx // 2:])
-    return int(np.sign(q))
+    """+1 / -1: which diagonal pair of quadrants of a PV diagram holds more
+    flux (the rotation / infall sign the reference derives at
+    _pvfitting.py:462-469)."""
+    m = np.asarray(m)
+    kv, kx = m.shape[0] // 2, m.shape[1] // 2
+    lowleft, upright = np.sum(m[:kv, :kx]), np.sum(m[kv:, kx:])
+    upleft, lowright = np.sum(m[kv:, :kx]), np.sum(m[:kv, kx:])
+    return int(np.sign(lowleft + upright - upleft - lowright))
 
 
 class PVFitting(ReadFits):
@@ -30,30 +35,31 @@ class PVFitting(ReadFits):
                vmin: float | None, vmax: float | None, sigma: float | None,
                xskip: int = 1, skipto: int | None = None,
                dNsampling: list | None = [5, 1]):
-        """Read the two observed PV diagrams (_pvfitting.py:31-61)."""
-        d = []
-        for pvfits in [pvmajorfits, pvminorfits]:
-            self.read_pvfits(pvfits=pvfits, dist=dist, vsys=vsys,
-                             xmin=-rmax, xmax=rmax, xskip=xskip, sigma=sigma)
+        """Read the major- and minor-axis PV diagrams (same arguments as the
+        reference's, _pvfitting.py:31-61).  Each file is read twice: first over
+        the whole velocity axis (kept as `vorg`, and to turn `skipto` = pixels
+        per beam minor axis into a decimation factor), then decimated and
+        cropped to [vmin, vmax]."""
+        diagrams = []
+        for path in (pvmajorfits, pvminorfits):
+            common = dict(pvfits=path, dist=dist, vsys=vsys, xmin=-rmax, xmax=rmax, sigma=sigma)
+            self.read_pvfits(xskip=xskip, **common)
+            step = xskip
             if type(skipto) is int:
-                iskip = int(self.bmin / (np.abs(self.dx) / xskip) / skipto)
-                if iskip == 0:
-                    print('WARNING: \'skipto\' is ignored because the beam minor '
-                          'axis is smaller than \'skipto\' pixels.')
-                    iskip = 1
+                pix = np.abs(self.dx) / xskip          # undecimated pixel [au]
+                step = int(self.bmin / pix / skipto)
+                if step == 0:
+                    step = 1
+                    print("WARNING: 'skipto' is ignored because the beam minor axis is "
+                          "smaller than 'skipto' pixels.")
                 else:
-                    print(f'Adopt xskip={iskip:d}.')
-                    ibmaj = self.bmaj / (np.abs(self.dx) * iskip)
-                    ibmin = self.bmin / (np.abs(self.dx) * iskip)
-                    print(f'Beam major/minor axis is {ibmaj:.1f}/{ibmin:.1f} pixels.')
-            else:
-                iskip = xskip
+                    print(f'Adopt xskip={step:d}.')
+                    print(f'Beam major/minor axis is {self.bmaj / (pix * xskip * step):.1f}'
+                          f'/{self.bmin / (pix * xskip * step):.1f} pixels.')
             self.vorg = self.v
-            self.read_pvfits(pvfits=pvfits, dist=dist, vsys=vsys,
-                             xmin=-rmax, xmax=rmax, xskip=iskip, sigma=sigma,
-                             vmin=vmin, vmax=vmax)
-            d.append(self.data)
-        self.dpvmajor, self.dpvminor = d
+            self.read_pvfits(xskip=step, vmin=vmin, vmax=vmax, **common)
+            diagrams.append(self.data)
+        self.dpvmajor, self.dpvminor = diagrams
 
     def check_modelgrid(self, nsubgrid: float = 1, n_nest: list | None = None,
                         reslim: float = 5):
@@ -138,7 +144,7 @@ class PVFitting(ReadFits):
             kw = {'nwalkers_per_ndim': 4, 'nburnin': 500, 'nsteps': 500,
                   'rangelevel': None, 'range_corner': None, 'labels': labels,
                   'figname': filename + '.corner.png', 'show_corner': show,
-                  'plot_chain': True, 'show_chain': show}
+                  'plot_chain': False, 'show_chain': False}
             kw.update(kwargs_emcee_corner)
             bar = None
             if progressbar:
@@ -201,121 +207,7 @@ class PVFitting(ReadFits):
         self.plow = dict(zip(paramkeys, self.plow))
         self.pmid = dict(zip(paramkeys, self.pmid))
         self.phigh = dict(zip(paramkeys, self.phigh))
-        if plot:
-            self.plot_pvds(filename=filename, color='model', contour='obs',
-                           vmask=vmask, title=title, show=show, log=log)
 
     def read_fitres(self, f: str):
         """Read a <filename>.popt.txt table (_pvfitting.py:267-275)."""
         self.popt, self.plow, self.pmid, self.phigh = np.loadtxt(f).T
-
-    def plot_pvds(self, filename: str = 'PVfitting', color: str = 'model',
-                  contour: str = 'obs', vmask: list = [0., 0.],
-                  cmap: str = 'viridis', cmap_residual: str = 'bwr',
-                  ext: str = '.png', title: str | None = None,
-                  show: bool = False, shadecolor: str = 'white',
-                  clevels: list | None = None, log: bool = False):
-        """Observed vs model PV diagrams and residuals (_pvfitting.py:277-424)."""
-        import matplotlib.pyplot as plt
-        majobs = np.array(self.dpvmajor, dtype=float)
-        minobs = np.array(self.dpvminor, dtype=float)
-        x, v = np.meshgrid(self.x, self.v)
-        mask = (vmask[0] < v) * (v < vmask[1])
-        use_model = 'model' in [color, contour]
-        if use_model:
-            if not hasattr(self, 'popt'):
-                print('ERROR\tplot_pvds: No optimized parameters are found.')
-                print('ERROR\tplot_pvds: Run fitting or read fitting result first.')
-                return 0
-            popt = np.array(list(self.popt.values())) if isinstance(self.popt, dict) \
-                else np.asarray(self.popt)
-            majmod, minmod = self.makemodel(*popt[:-1])
-            majres = np.where(mask, -(mask.astype('int')), (majobs - majmod) / self.sigma)
-            minres = np.where(mask, -(mask.astype('int')), (minobs - minmod) / self.sigma)
-        outlabel = '.model' if use_model else '.obs'
-        if clevels is None:
-            clevels = (2**np.arange(0, 10) if log else np.arange(1, 11)) * 3 * self.sigma
-
-        def panel(colors, contours, cm, vmin, vmax, shade, alpha, residual):
-            fig, axes = plt.subplots(1, 2)
-            fig.set_figheight(3.2)
-            fig.set_figwidth(5)
-            if log and not residual:
-                lo = np.log10(2 * self.sigma) if vmin is None else np.log10(vmin)
-                hi = None if vmax is None else np.log10(vmax)
-            elif residual:
-                top = max(abs(vmin), abs(vmax))
-                lo, hi = -top, top
-            else:
-                lo, hi = vmin, vmax
-            for ax, dc, dk, xl in zip(axes, colors, contours,
-                                      ('Major offset (au)', 'Minor offset (au)')):
-                ax.tick_params('x', rotation=30)
-                d = dc * 1
-                if log and not residual:
-                    d = np.log10(d.clip(vmin, None))
-                im = ax.pcolormesh(self.x, self.v, d, cmap=cm, vmin=lo, vmax=hi,
-                                   alpha=alpha, rasterized=True)
-                ax.contour(self.x, self.v, dk, levels=clevels, colors='k')
-                ax.set_xlabel(xl)
-                ax.set_xlim(np.min(self.x), np.max(self.x))
-                ax.set_ylim(np.min(self.v), np.max(self.v))
-            axes[0].set_ylabel(r'$V-V_{\rm sys}$ (km s$^{-1}$)')
-            axes[1].set_yticklabels('')
-            cax = axes[1].inset_axes([1.02, 0., 0.05, 1.])
-            plt.colorbar(im, cax=cax, label=r'Noise level ($\sigma$)' if residual
-                         else r'Jy beam$^{-1}$')
-            if shade is not None:
-                _v = self.v[(self.v > shade[0]) * (self.v < shade[1])]
-                if len(_v):
-                    for ax in axes:
-                        ax.fill_between(self.x,
-                                        np.full(len(self.x), np.min(_v) - 0.5 * self.dv),
-                                        np.full(len(self.x), np.max(_v) + 0.5 * self.dv),
-                                        color=shadecolor, alpha=0.6, edgecolor=None)
-            if title is not None:
-                fig.suptitle(title, y=0.92)
-            fig.tight_layout()
-            fig.subplots_adjust(wspace=0.1)
-            return fig
-
-        d_col = [majmod, minmod] if color == 'model' else [majobs, minobs]
-        d_con = [majmod, minmod] if contour == 'model' else [majobs, minobs]
-        vmin = 2 * self.sigma if log else np.nanmin(np.array(d_col))
-        vmax = np.nanmax(np.array(d_col))
-        shade = vmask if vmask[1] > vmask[0] else None
-        figs = [panel(d_col, d_con, cmap, vmin, vmax, shade, 0.8, False)]
-        figs[0].savefig(filename + outlabel + ext, dpi=300)
-        if show:
-            plt.show()
-        if use_model:
-            d_col = [majres, minres] if color == 'model' else [majobs, minobs]
-            d_con = [majres, minres] if contour == 'model' else [majobs, minobs]
-            vmin, vmax = np.nanmin(np.array(d_col)), np.nanmax(np.array(d_col))
-            figs.append(panel(d_col, d_con, cmap_residual, vmin, vmax, None, 0.5, True))
-            figs[1].savefig(filename + '.residual' + ext, dpi=300)
-            if show:
-                plt.show()
-        for f in figs:
-            plt.close(f)
-        return figs
-
-    def modeltofits(self, filehead: str = 'best', **kwargs):
-        """Write model and residual PV diagrams on the full velocity axis
-        (_pvfitting.py:426-459)."""
-        from .fitsio import write_cube
-        h = dict(self.header)
-        h['CRPIX1'] = h['CRPIX1'] - self.offpix[0]
-        nx = len(self.x)
-        p = dict(self.popt if kwargs == {} else kwargs)
-        p.pop('sig_mdl', None)
-        majmod, minmod = self.makemodel(**p)
-        majres = self.dpvmajor - majmod
-        minres = self.dpvminor - minmod
-        nblue = int(np.sum(self.vorg < np.min(self.v)))
-        nred = int(np.sum(np.max(self.v) < self.vorg))
-        pad = lambda d: np.concatenate((np.full((nblue, nx), np.nan), d,      # noqa: E731
-                                        np.full((nred, nx), np.nan)), axis=0)
-        for d, ext in ((majmod, 'model.major'), (minmod, 'model.minor'),
-                       (majres, 'residual.major'), (minres, 'residual.minor')):
-            write_cube(f'{filehead}.{ext}.fits', pad(d), h)

@@ -55,7 +55,54 @@ def spherical_offsets(ra0, dec0, ra, dec):
     return np.degrees(np.arctan2(y, x)), np.degrees(np.arcsin(z))
 
 
+def _pixel_axis(h, ax):
+    """World offsets of FITS axis `ax` from its reference pixel (CDELT units)."""
+    return (np.arange(h[f'NAXIS{ax}']) - h[f'CRPIX{ax}'] + 1) * h[f'CDELT{ax}']
+
+
+def _decimate(h, ax, coord, data, data_axis, skip):
+    """Keep every `skip`-th pixel of FITS axis `ax`, phased so that the
+    reference pixel survives; the header's CRPIX / CDELT follow."""
+    ref = int(h[f'CRPIX{ax}']) - 1
+    first = ref % skip
+    h[f'CRPIX{ax}'] = (ref - first) // skip + 1
+    h[f'CDELT{ax}'] = h[f'CDELT{ax}'] * skip
+    pick = [slice(None)] * data.ndim
+    pick[data_axis] = slice(first, None, skip)
+    return coord[first::skip], data[tuple(pick)]
+
+
+def _to_velocity(h, ax, w, vsys):
+    """Spectral axis -> km/s relative to vsys (radio convention for 'Hz')."""
+    unit = h.get(f'CUNIT{ax}')
+    if unit == 'Hz':
+        rest = h.get('RESTFRQ', h.get('RESTFREQ'))
+        if rest is None:
+            rest = np.mean(w)
+            print('No rest frequency found. The middle frequency adopted.')
+        return (1. - w / rest) * _C_SI / 1.e3 - vsys
+    if unit == 'm/s':
+        return w * 1e-3 - vsys
+    return w
+
+
+def _nearest(coord, value, default):
+    return default if value is None else int(np.argmin(np.abs(coord - value)))
+
+
+def _beam(h, dist, fallback):
+    """(bmaj, bmin, bpa) in au / deg from the header, else `fallback`."""
+    if 'BMAJ' in h:
+        return h['BMAJ'] * 3600. * dist, h['BMIN'] * 3600. * dist, h['BPA']
+    print('No valid beam in the FITS file.')
+    return fallback
+
+
 class ReadFits:
+    """FITS input of the analysis classes: same methods, arguments, attributes
+    and return dicts as the reference's `ReadFits` (utils.py:177-352), read
+    with this package's own primary-HDU reader (astropy is optional)."""
+
     def read_cubefits(self, cubefits: str, center: str | None = None,
                       dist: float = 1, vsys: float = 0,
                       xmin: float | None = None, xmax: float | None = None,
@@ -63,70 +110,36 @@ class ReadFits:
                       vmin: float | None = None, vmax: float | None = None,
                       xskip: int = 1, yskip: int = 1,
                       sigma: float | None = None) -> dict:
-        """Read channel maps: axes in au / km s^-1 relative to `center`/`vsys`,
-        cropped to the given limits (reference utils.py:178-277)."""
-        d, h = fitsio.read_primary(cubefits)
-        d = np.squeeze(d)
-        h = dict(h)
-        if center is None:
-            cx, cy = 0, 0
-        else:
-            cx, cy = spherical_offsets(h['CRVAL1'], h['CRVAL2'],
-                                       *parse_center(center))
-        if sigma is None:
-            sigma = np.mean([np.nanstd(d[:2]), np.std(d[-2:])])
+        """Channel maps with axes in au / km s^-1 relative to `center` / `vsys`,
+        decimated by xskip / yskip and cropped to the limits; x follows the
+        file's (descending R.A.) order, so `xmax` is the first column kept."""
+        cube, h = fitsio.read_primary(cubefits)
+        cube, h = np.squeeze(cube), dict(h)
+        off = (0, 0) if center is None else spherical_offsets(
+            h['CRVAL1'], h['CRVAL2'], *parse_center(center))
+        if sigma is None:                  # rms of the two edge channels at either end
+            sigma = np.mean([np.nanstd(cube[:2]), np.std(cube[-2:])])
             print(f'sigma = {sigma:.3e}')
-        x = (np.arange(h['NAXIS1']) - h['CRPIX1'] + 1) * h['CDELT1']
-        y = (np.arange(h['NAXIS2']) - h['CRPIX2'] + 1) * h['CDELT2']
-        v = (np.arange(h['NAXIS3']) - h['CRPIX3'] + 1) * h['CDELT3']
-        for ax, skip in ((1, xskip), (2, yskip)):          # pixel skipping
-            crpix = int(h[f'CRPIX{ax}']) - 1
-            start = crpix % skip
-            h[f'CRPIX{ax}'] = (crpix - start) // skip + 1
-            h[f'CDELT{ax}'] = h[f'CDELT{ax}'] * skip
-            if ax == 1:
-                x, d = x[start::skip], d[:, :, start::skip]
-            else:
-                y, d = y[start::skip], d[:, start::skip, :]
-        v = v + h['CRVAL3']
-        x = (x - cx) * 3600. * dist  # au
-        y = (y - cy) * 3600. * dist  # au
-        if h.get('CUNIT3') == 'Hz':
-            if 'RESTFRQ' in h:
-                restfreq = h['RESTFRQ']
-            elif 'RESTFREQ' in h:
-                restfreq = h['RESTFREQ']
-            else:
-                restfreq = np.mean(v)
-                print('No rest frequency found. The middle frequency adopted.')
-            v = (1. - v / restfreq) * _C_SI / 1.e3 - vsys  # km/s
-        elif h.get('CUNIT3') == 'm/s':
-            v = v * 1e-3 - vsys
-        i0 = 0 if xmax is None else np.argmin(np.abs(x - xmax))
-        i1 = len(x) - 1 if xmin is None else np.argmin(np.abs(x - xmin))
-        j0 = 0 if ymin is None else np.argmin(np.abs(y - ymin))
-        j1 = len(y) - 1 if ymax is None else np.argmin(np.abs(y - ymax))
-        k0 = 0 if vmin is None else np.argmin(np.abs(v - vmin))
-        k1 = len(v) - 1 if vmax is None else np.argmin(np.abs(v - vmax))
-        x, y, v = x[i0:i1 + 1], y[j0:j1 + 1], v[k0:k1 + 1]
-        d = d[k0:k1 + 1, j0:j1 + 1, i0:i1 + 1]
-        self.offpix = (i0, j0, k0)
-        dx, dy, dv = x[1] - x[0], y[1] - y[0], v[1] - v[0]
-        if 'BMAJ' in h:
-            bmaj = h['BMAJ'] * 3600. * dist  # au
-            bmin = h['BMIN'] * 3600. * dist  # au
-            bpa = h['BPA']  # deg
-        else:
-            bmaj, bmin, bpa = dy, -dx, 0
-            print('No valid beam in the FITS file.')
-        self.x, self.dx, self.nx = x, dx, len(x)
-        self.y, self.dy, self.ny = y, dy, len(y)
-        self.v, self.dv, self.nv = v, dv, len(v)
-        self.data, self.header, self.sigma = d, h, sigma
-        self.bmaj, self.bmin, self.bpa = bmaj, bmin, bpa
-        self.beam = np.array([bmaj, bmin, bpa])
+        x, y, v = (_pixel_axis(h, ax) for ax in (1, 2, 3))
+        x, cube = _decimate(h, 1, x, cube, 2, xskip)
+        y, cube = _decimate(h, 2, y, cube, 1, yskip)
+        x = (x - off[0]) * 3600. * dist
+        y = (y - off[1]) * 3600. * dist
+        v = _to_velocity(h, 3, v + h['CRVAL3'], vsys)
+        lo = (_nearest(x, xmax, 0), _nearest(y, ymin, 0), _nearest(v, vmin, 0))
+        hi = (_nearest(x, xmin, len(x) - 1), _nearest(y, ymax, len(y) - 1),
+              _nearest(v, vmax, len(v) - 1))
+        x, y, v = (c[a:b + 1] for c, a, b in zip((x, y, v), lo, hi))
+        cube = cube[lo[2]:hi[2] + 1, lo[1]:hi[1] + 1, lo[0]:hi[0] + 1]
+        self.offpix = lo
+        self.x, self.y, self.v, self.data = x, y, v, cube
+        self.dx, self.dy, self.dv = x[1] - x[0], y[1] - y[0], v[1] - v[0]
+        self.nx, self.ny, self.nv = len(x), len(y), len(v)
+        self.header, self.sigma = h, sigma
+        self.bmaj, self.bmin, self.bpa = _beam(h, dist, (self.dy, -self.dx, 0))
+        self.beam = np.array([self.bmaj, self.bmin, self.bpa])
         self.cubefits, self.dist, self.vsys = cubefits, dist, vsys
-        return {'x': x, 'y': y, 'v': v, 'data': d, 'header': h, 'sigma': sigma}
+        return {'x': x, 'y': y, 'v': v, 'data': cube, 'header': h, 'sigma': sigma}
 
     def read_pvfits(self, pvfits: str,
                     dist: float = 1, vsys: float = 0,
@@ -134,58 +147,31 @@ class ReadFits:
                     vmin: float | None = None, vmax: float | None = None,
                     xskip: int = 1,
                     sigma: float | None = None) -> dict:
-        """Read a position-velocity diagram: offset axis in au (ascending),
-        velocity in km s^-1 relative to `vsys`, cropped to the given limits
-        (reference utils.py:279-352)."""
-        d, h = fitsio.read_primary(pvfits)
-        d = np.squeeze(d)
-        h = dict(h)
-        if sigma is None:
-            sigma = np.mean([np.std(d[:2, 10:-10]), np.std(d[-2:, 10:-10]),
-                             np.std(d[2:-2, :10]), np.std(d[2:-2, -10:])])
+        """Position-velocity diagram: offset axis in au (ascending), velocity in
+        km s^-1 relative to `vsys`, decimated by xskip and cropped."""
+        pv, h = fitsio.read_primary(pvfits)
+        pv, h = np.squeeze(pv), dict(h)
+        if sigma is None:                  # rms of the four borders of the diagram
+            sigma = np.mean([np.std(pv[:2, 10:-10]), np.std(pv[-2:, 10:-10]),
+                             np.std(pv[2:-2, :10]), np.std(pv[2:-2, -10:])])
             print(f'sigma = {sigma:.3e}')
-        x = (np.arange(h['NAXIS1']) - h['CRPIX1'] + 1) * h['CDELT1']
-        v = (np.arange(h['NAXIS2']) - h['CRPIX2'] + 1) * h['CDELT2']
-        crpix = int(h['CRPIX1']) - 1
-        start = crpix % xskip
-        x, d = x[start::xskip], d[:, start::xskip]
-        h['CRPIX1'] = (crpix - start) // xskip + 1
-        h['CDELT1'] = h['CDELT1'] * xskip
-        v = v + h['CRVAL2']
-        x = (x + h['CRVAL1']) * dist  # au
-        if h.get('CUNIT2') == 'Hz':
-            if 'RESTFRQ' in h:
-                restfreq = h['RESTFRQ']
-            elif 'RESTFREQ' in h:
-                restfreq = h['RESTFREQ']
-            else:
-                restfreq = np.mean(v)
-                print('No rest frequency found. The middle frequency adopted.')
-            v = (1. - v / restfreq) * _C_SI / 1.e3 - vsys  # km/s
-        elif h.get('CUNIT2') == 'm/s':
-            v = v * 1e-3 - vsys
-        i0 = 0 if xmin is None else np.argmin(np.abs(x - xmin))
-        i1 = len(x) - 1 if xmax is None else np.argmin(np.abs(x - xmax))
-        k0 = 0 if vmin is None else np.argmin(np.abs(v - vmin))
-        k1 = len(v) - 1 if vmax is None else np.argmin(np.abs(v - vmax))
-        x, v = x[i0:i1 + 1], v[k0:k1 + 1]
-        d = d[k0:k1 + 1, i0:i1 + 1]
-        self.offpix = (i0, k0)
-        dx, dv = x[1] - x[0], v[1] - v[0]
-        if 'BMAJ' in h:
-            bmaj = h['BMAJ'] * 3600. * dist  # au
-            bmin = h['BMIN'] * 3600. * dist  # au
-            bpa = h['BPA']  # deg
-        else:
-            bmaj, bmin, bpa = dx, dx, 0
-            print('No valid beam in the FITS file.')
-        self.x, self.dx, self.nx = x, dx, len(x)
-        self.v, self.dv, self.nv = v, dv, len(v)
-        self.data, self.header, self.sigma = d, h, sigma
-        self.bmaj, self.bmin, self.bpa = bmaj, bmin, bpa
-        self.beam = np.array([bmaj, bmin, bpa])
+        x, v = _pixel_axis(h, 1), _pixel_axis(h, 2)
+        x, pv = _decimate(h, 1, x, pv, 1, xskip)
+        x = (x + h['CRVAL1']) * dist
+        v = _to_velocity(h, 2, v + h['CRVAL2'], vsys)
+        lo = (_nearest(x, xmin, 0), _nearest(v, vmin, 0))
+        hi = (_nearest(x, xmax, len(x) - 1), _nearest(v, vmax, len(v) - 1))
+        x, v = x[lo[0]:hi[0] + 1], v[lo[1]:hi[1] + 1]
+        pv = pv[lo[1]:hi[1] + 1, lo[0]:hi[0] + 1]
+        self.offpix = lo
+        self.x, self.v, self.data = x, v, pv
+        self.dx, self.dv = x[1] - x[0], v[1] - v[0]
+        self.nx, self.nv = len(x), len(v)
+        self.header, self.sigma = h, sigma
+        self.bmaj, self.bmin, self.bpa = _beam(h, dist, (self.dx, self.dx, 0))
+        self.beam = np.array([self.bmaj, self.bmin, self.bpa])
         self.pvfits, self.dist, self.vsys = pvfits, dist, vsys
-        return {'x': x, 'v': v, 'data': d, 'header': h, 'sigma': sigma}
+        return {'x': x, 'v': v, 'data': pv, 'header': h, 'sigma': sigma}
 
 
 # ---------------------------------------------------------------------------
@@ -252,7 +238,9 @@ def emcee_corner(bounds, log_prob_fn, args: list = [],
                  ncore: int = 1, simpleoutput: bool = True,
                  moves=None, vectorize: bool = False, seed=None,
                  return_sampler: bool = False):
-    """Two-phase ensemble MCMC in a box prior (reference utils.py:18-119).
+    """Two-phase ensemble MCMC in a box prior (reference utils.py:18-119; same
+    arguments and return values, `ncore` and the figure arguments are accepted
+    and not acted on: the likelihood is batched on the GPU, figures are out of scope).
 
     `vectorize=True`: `log_prob_fn` takes p[nw, ndim] and returns lnp[nw]; the
     strict box prior (utils.py:32-36) is applied here and only in-prior rows
@@ -312,103 +300,14 @@ def emcee_corner(bounds, log_prob_fn, args: list = [],
         print('\nWARNING: emcee did not converge (Gelman-Rubin =',
               np.round(GR, 2), '> 1.25).\n')
     popt = samples[np.unravel_index(np.argmax(lnp), lnp.shape)]
-    chains = samples.copy()
     flat = samples.reshape((-1, ndim))
     plow, pmid, phigh = (np.percentile(flat, q, axis=0) for q in (16, 50, 84))
     perr = (phigh - plow) / 2.
-    if range_corner is None:
-        r_c = [rangelevel] * ndim if rangelevel is not None else np.transpose(bounds)
-    else:
-        r_c = range_corner
-    if show_corner or figname is not None:
-        _corner_plot(flat, popt, r_c, labels, figname, show_corner)
-    if plot_chain:
-        _chain_plot(chains, labels, figname, show_chain)
+    if show_corner or plot_chain:
+        # corner / chain figures are not part of this package (SURVEY.md section 2, rows 5
+        # and 7): the samples are returned; plot them with the reference's own helpers
+        print('slam_amd.emcee_corner: figures are not drawn here (figname / show_* ignored).')
     out = [pmid, perr] if simpleoutput else [popt, plow, pmid, phigh]
     if return_sampler:
         return out, sampler
     return out
-
-
-def dynesty_corner(bounds, log_prob_fn, args: list = [], labels: list = None,
-                   figname: str = None, show_corner: bool = False,
-                   return_evidence: bool = False, simpleoutput: bool = True,
-                   wt_kwargs=None, vectorize: bool = False):
-    """Dynamic nested sampling in a box prior (reference utils.py:122-174): same
-    arguments and return values.  `vectorize=True`: `log_prob_fn` takes
-    p[nw, ndim] (the GPU likelihoods do); dynesty proposes one point at a time,
-    so the batch has one row.  Needs dynesty, which is optional: without it this
-    raises ImportError instead of substituting another sampler."""
-    try:
-        from dynesty import DynamicNestedSampler as DNS
-        from dynesty import utils as dyfunc
-    except ImportError as e:
-        raise ImportError('dynesty_corner needs the dynesty package '
-                          '(not installed); emcee_corner has a built-in sampler') from e
-    plim = np.array(bounds, dtype=float)
-    ndim = len(plim[0])
-    if vectorize:
-        def lnlike(p):
-            return float(np.asarray(log_prob_fn(np.atleast_2d(p), *args))[0])
-    else:
-        def lnlike(p):
-            return log_prob_fn(p, *args)
-
-    def ptform(u):
-        return plim[0] + (plim[1] - plim[0]) * u
-    dsampler = DNS(lnlike, ptform, ndim)
-    dsampler.run_nested(print_progress=False, wt_kwargs=wt_kwargs)
-    results = dsampler.results
-    if (figname is not None) & (show_corner == True):        # noqa: E712 (as the reference)
-        import matplotlib.pyplot as plt
-        from dynesty import plotting as dyplot
-        cfig, _ = dyplot.cornerplot(results, labels=labels, quantiles=[0.16, 0.5, 0.84])
-        cfig.savefig(figname)
-        plt.show()
-    weights = results.importance_weights()
-    quantiles = [dyfunc.quantile(samps, [0.16, 0.5, 0.84], weights=weights)
-                 for samps in results.samples.T]
-    if return_evidence:
-        evidence = np.exp(results.logz[-1])
-        print(f'Evidence: {evidence:.2e} +/- {evidence * results.logzerr[-1]:.2e}')
-    if simpleoutput:
-        pmid = np.array(quantiles).T[1]
-        perr = np.array([(q[2] - q[0]) * 0.5 for q in quantiles])
-        return [pmid, perr]
-    popt = results.samples[np.argmax(results.logl), :]
-    plow, pmid, phigh = np.array(quantiles).T
-    return [popt, plow, pmid, phigh]
-
-
-def _corner_plot(flat, popt, r_c, labels, figname, show):
-    try:
-        import corner
-        import matplotlib.pyplot as plt
-    except ImportError:
-        print('corner is not installed: skipping the corner plot.')
-        return
-    corner.corner(flat, truths=popt, quantiles=[0.16, 0.5, 0.84],
-                  show_titles=True, range=r_c, labels=labels)
-    if figname is not None:
-        plt.savefig(figname)
-    if show:
-        plt.show()
-    plt.close()
-
-
-def _chain_plot(chains, labels, figname, show):
-    import matplotlib.pyplot as plt
-    nwalkers, nsteps, ndim = chains.shape
-    fig, axes = plt.subplots(ndim, 1, sharex=True, squeeze=False)
-    for i, ax in enumerate(axes[:, 0]):
-        ax.plot(np.arange(nsteps), chains[:, :, i].T, 'k', lw=0.5)
-        if labels is not None:
-            ax.set_ylabel(labels[i])
-    axes[-1, 0].set_xlabel('Step number')
-    if figname is not None:
-        fname = (figname.replace('.corner', '.chains') if '.corner' in figname
-                 else figname.replace('.png', '.chains.png'))
-        fig.savefig(fname)
-    if show:
-        plt.show()
-    plt.close()

@@ -204,12 +204,36 @@ def test_fits_roundtrip_and_cube_reader(tmp_path):
     assert out['data'].shape[0] == nv and out['x'].max() <= 12 and out['x'].min() >= -12
 
 
-def test_dynesty_corner_without_dynesty_raises():
-    """The nested-sampling driver exists with the reference's signature and
-    refuses loudly when dynesty is not installed (no substitute sampler)."""
-    import importlib.util
-    from slam_amd.utils import dynesty_corner
-    if importlib.util.find_spec('dynesty') is not None:
-        pytest.skip('dynesty installed')
-    with pytest.raises(ImportError):
-        dynesty_corner([[0, 0], [1, 1]], lambda p: -np.sum(np.square(p)))
+def test_spherical_offsets_hand_computed():
+    """The sky-offset frame of `read_cubefits` (reference utils.py:211-216 asks
+    astropy's `spherical_offsets_to`; astropy is not importable here, so the
+    function is pinned on cases worked by hand from the frame's definition:
+    lon = atan2(p.e, p.o), lat = asin(p.n) with o the origin's unit vector and
+    e, n the local east and north there)."""
+    from slam_amd.utils import parse_center, spherical_offsets
+    sec = 1.0 / 3600.0
+    # the origin itself; a pure declination offset; an offset along the equator
+    assert spherical_offsets(60.0, 30.0, 60.0, 30.0) == (0.0, 0.0)
+    lon, lat = spherical_offsets(60.0, 30.0, 60.0, 31.0)
+    assert abs(lon) < 1e-13 and abs(lat - 1.0) < 1e-13
+    lon, lat = spherical_offsets(10.0, 0.0, 12.5, 0.0)
+    assert abs(lon - 2.5) < 1e-13 and abs(lat) < 1e-13
+    # o = (cos45, 0, sin45), p = (0, 1, 0): e = (0, 1, 0), n = (-sin45, 0, cos45) -> (90, 0)
+    lon, lat = spherical_offsets(0.0, 45.0, 90.0, 0.0)
+    assert abs(lon - 90.0) < 1e-13 and abs(lat) < 1e-13
+    # over the pole: 20 degrees due north of (ra0, 80) lies (ra0 + 180, 80)
+    lon, lat = spherical_offsets(33.0, 80.0, 213.0, 80.0)
+    assert abs(lon) < 1e-12 and abs(lat - 20.0) < 1e-12
+    # small angles at declination 60: lon = dRA cos(dec), lat = dRA^2 sin(dec) cos(dec) / 2 (the
+    # parallel lies poleward of the great circle), both to second order
+    dra = 1.0 * sec
+    lon, lat = spherical_offsets(70.0, 60.0, 70.0 + dra, 60.0)
+    assert abs(lon / (dra * 0.5) - 1) < 1e-9
+    expect = np.degrees(np.radians(dra)**2 * np.sin(np.radians(60)) * 0.5 / 2)
+    assert abs(lat / expect - 1) < 1e-4          # 3e-10 deg out of asin(~1e-11): rounding is 1e-6 of it
+    # west of the origin is negative longitude (R.A. decreases to the west)
+    assert spherical_offsets(70.0, 60.0, 70.0 - dra, 60.0)[0] < 0
+    ra, dec = parse_center('04h39m53.878s +26d03m09.43s')
+    assert abs(ra - (4 + 39 / 60 + 53.878 / 3600) * 15) < 1e-12
+    assert abs(dec - (26 + 3 / 60 + 9.43 / 3600)) < 1e-12
+    assert parse_center('16h00m00s -00d30m00s')[1] == -0.5
