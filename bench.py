@@ -88,9 +88,12 @@ def main():
         if world > 1:
             dist.destroy_process_group()
         return
+    t_start = time.perf_counter()
     fit = synth.make_fit(args.config, bpa=args.bpa, scaling=args.scaling,
                          envelope=args.workload == 'envelope', precision=args.dtype)
     eng = fit.engine
+    torch.cuda.synchronize()
+    startup_s = time.perf_counter() - t_start   # per rank: synthetic cube, makegrid, context
     nw_total = args.walkers * world
     P = synth.walkers(nw_total, workload=args.workload) if rank == 0 else None
     sharded = ShardedLikelihood(eng.chi2_batch_torch, device='cuda')
@@ -110,9 +113,9 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        t = torch.tensor([dt, startup_s], dtype=torch.float64, device='cuda')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dt, startup_s = float(t[0].item()), float(t[1].item())
     chi2 = chi2.cpu().numpy()
 
     if rank == 0:
@@ -137,6 +140,7 @@ def main():
             except Exception as e:              # dense conv mode etc.: no accounting
                 counts = None
         out = report(args, fit, eng, world, nw_total, dt, chi2, kern, psteps, counts)
+        out['config']['startup_s_per_rank'] = round(startup_s, 3)   # max over ranks, outside the timed region
         if world == 1 and args.cpu_evals > 0:
             out['cpu_baseline'] = cpu_baseline(fit, P, chi2, args.cpu_evals)
             if multi is not None:

@@ -156,6 +156,16 @@ int slamhip_chi2_stats(slamhip_ctx* ctx, const double* params, int nw,
 int slamhip_cubemodel(slamhip_ctx* ctx, const double* params, int convolving,
                       double* out, double* stats_out);
 
+/* Replaces the data half of `ChannelFit.plotmom` (:720-737): the model cube of
+ * `params` as slamhip_cubemodel(convolving = 1) builds it, reduced over its
+ * channels on the device as `makemom01` (:40-50) does: mom0 = sum_k(d) * dv,
+ * mom1 = sum_k(d * v) / sum_k(d), NaN where mom0 < clip (the caller passes
+ * 3 * sigma_mom0).  Channels are added in order and products rounded first, so
+ * both maps equal numpy's on the same cube bit for bit.  `mom0_out`, `mom1_out`
+ * are host buffers [ny][nx].  Synchronous. */
+int slamhip_moments(slamhip_ctx* ctx, const double* params, double dv, double clip,
+                    double* mom0_out, double* mom1_out);
+
 /* Parity taps.  `get_Iunif` output (:454-473) [nv][nneed][nneed], and the
  * beam-convolved cube (:530) on the same grid. */
 int slamhip_iunif(slamhip_ctx* ctx, const double* params, double* out);

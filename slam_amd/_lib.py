@@ -51,6 +51,7 @@ SYMBOLS = {
                                       C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
     'slamhip_chi2_stats': (C.c_int, [C.c_void_p, _dp, C.c_int, _dp]),
     'slamhip_cubemodel': (C.c_int, [C.c_void_p, _dp, C.c_int, _dp, _dp]),
+    'slamhip_moments': (C.c_int, [C.c_void_p, _dp, C.c_double, C.c_double, _dp, _dp]),
     'slamhip_iunif': (C.c_int, [C.c_void_p, _dp, _dp]),
     'slamhip_iconv': (C.c_int, [C.c_void_p, _dp, _dp]),
     'slamhip_surface': (C.c_int, [C.c_void_p, _dp, C.c_int, _dp, _dp]),

@@ -41,16 +41,22 @@ SCALINGS = ('uniform', 'mom0ft', 'mom0clean', 'mom0model')
 
 
 def makemom01(d, v, sigma):
-    """Moment 0/1 maps of a cube (:40-50)."""
+    """Moment maps of a cube over its channel axis, as the reference's helper of
+    the same name returns them (:40-50): `mom0` = sum(d) dv with dv the smallest
+    channel step, `mom1` = sum(d v) / sum(d), blanked (NaN) where mom0 is under
+    3 `sigma_mom0` = 3 sigma dv sqrt(channels), and `mom2` = sqrt(sum(d (v - mom1)^2))
+    (the reference's second argument to np.sqrt is an output buffer, not a divisor)."""
+    v = np.asarray(v)
+    dv = np.diff(v).min()
+    vcol = v.reshape(-1, 1, 1)
     with np.errstate(all='ignore'):
-        dv = np.min(v[1:] - v[:-1])
-        mom0 = np.sum(d, axis=0) * dv
+        total = np.sum(d, axis=0)
+        mom0 = total * dv
+        mom1 = np.sum(d * vcol, axis=0) / total
+        mom2 = np.sqrt(np.sum(d * (vcol - mom1)**2, axis=0))
         sigma_mom0 = sigma * dv * np.sqrt(len(d))
-        vv = np.asarray(v)[:, None, None]
-        mom1 = np.sum(d * vv, axis=0) / np.sum(d, axis=0)
-        mom2 = np.sqrt(np.sum(d * (vv - mom1)**2, axis=0), np.sum(d, axis=0))
         mom1[mom0 < 3 * sigma_mom0] = np.nan
-    return {'mom0': mom0, 'mom1': mom1, 'mom2': mom2, 'sigma_mom0': sigma_mom0}
+    return dict(mom0=mom0, mom1=mom1, mom2=mom2, sigma_mom0=sigma_mom0)
 
 
 class ChannelFit(ReadFits):
@@ -275,6 +281,26 @@ class ChannelFit(ReadFits):
         p = self._natural(Mstar, Rc, cs, h1, h2, pI, Rin, Ienv, xoff, yoff,
                           voff, incloff, paoff)
         return self.engine.cubemodel(p, convolving=convolving)
+
+    def modelmom(self, mode: str = 'mod', **kwargs):
+        """(mom0, mom1) that the reference's `plotmom(mode)` draws (:720-737):
+        'obs' the observed maps of `makegrid`, 'mod' the model's for `self.popt`
+        (or the parameters given, which then become `self.popt` as there), 'res'
+        observed minus model.  The model cube is built and reduced over its
+        channels on the GPU (`slamhip_moments`); the figure itself is out of
+        this package's scope."""
+        if 'obs' in mode:
+            return self.mom0, self.mom1
+        if not ('mod' in mode or 'res' in mode):
+            raise ValueError("mode must contain 'obs', 'mod' or 'res'")
+        if kwargs != {}:
+            self.popt = kwargs
+        p = self._natural(**self.popt)
+        dv = np.diff(np.asarray(self.v_valid)).min()
+        mom0, mom1 = self.engine.moments(p, dv, 3 * self.sigma_mom0)
+        if 'res' in mode:
+            return self.mom0 - mom0, self.mom1 - mom1
+        return mom0, mom1
 
     def chi2_batch(self, P):
         """chi2 (:601-602) for natural-unit parameter rows P[nw, 13]."""

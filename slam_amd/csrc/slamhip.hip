@@ -2380,6 +2380,27 @@ __global__ void k_widen(const float* __restrict__ in, double* __restrict__ out, 
     out[e] = (double)in[e];
 }
 
+// Moment 0 and 1 of a model cube over its channels (reference makemom01,
+// _channelfit.py:40-50, as plotmom :724-725 asks for it): per pixel the channels
+// are added in order, products rounded before they are added, as numpy's
+// np.sum(d, axis=0) and np.sum(d * v, axis=0) do, so the maps are the
+// reference's bit for bit; mom1 is NaN where mom0 < clip (= 3 sigma_mom0).
+__global__ void __launch_bounds__(256)
+k_moments(const double* __restrict__ cube, const double* __restrict__ v, int nv, long long npix,
+          double dv, double clip, double* __restrict__ mom0, double* __restrict__ mom1) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= npix) return;
+  double s = 0.0, sv = 0.0;
+  for (int c = 0; c < nv; ++c) {
+    const double d = cube[(size_t)c * npix + i];
+    s = __dadd_rn(s, d);
+    sv = __dadd_rn(sv, __dmul_rn(d, v[c]));
+  }
+  const double m0 = __dmul_rn(s, dv);
+  mom0[i] = m0;
+  mom1[i] = m0 < clip ? __builtin_nan("") : __ddiv_rn(sv, s);
+}
+
 __global__ void k_scale(double* __restrict__ cube, long long n,
                         const double* __restrict__ stats) {
   const double s = stats[2];
@@ -3634,28 +3655,21 @@ int slamhip_iconv(slamhip_ctx* c, const double* params, double* out) {
   return single_finish(c, hipMemcpyAsync(out, c->d_iconv, nb, hipMemcpyDeviceToHost, c->stream), "iconv");
 }
 
-int slamhip_cubemodel(slamhip_ctx* c, const double* params, int convolving,
-                      double* out, double* stats_out) {
-  int rc = single_prepare(c, params);
-  if (rc) return rc;
-  if (!out) return fail(c, SLAMHIP_ERR_ARG, "null output");
+// One walker's model cube (the parameters already in the context's scratch set)
+// left in c->d_cube on the context's stream; *has_stats tells whether S.stats
+// holds (gf, ff, scale, chi2) for it.  The buffer is kept for later calls and
+// carries two [ny][nx] maps behind the cube for slamhip_moments.
+static int cube_on_device(slamhip_ctx* c, int convolving, bool* has_stats) {
   const FitK& k = c->k;
   Scratch& S = c->own;
   const size_t ncube = (size_t)k.nv * k.ny * k.nx;
-  if (!c->d_cube && (rc = dev_alloc(c, &c->d_cube, ncube))) return rc;   // kept for later calls
+  int rc;
+  if (!c->d_cube && (rc = dev_alloc(c, &c->d_cube, ncube + 2 * (size_t)k.ny * k.nx))) return rc;
   double* d_cube = c->d_cube;
+  *has_stats = true;
   if (k.mom0decon) {
-    rc = run_group_mom0(c, S, S.params, 1, S.chi2, d_cube, convolving != 0, c->stream);
-    if (rc) return rc;
-    hipError_t e = hipMemcpyAsync(out, d_cube, ncube * sizeof(double), hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess && stats_out) {
-      if (convolving) {
-        e = hipMemcpyAsync(stats_out, S.stats, 4 * sizeof(double), hipMemcpyDeviceToHost, c->stream);
-      } else {
-        for (int i = 0; i < 4; ++i) stats_out[i] = std::numeric_limits<double>::quiet_NaN();
-      }
-    }
-    return single_finish(c, e, "cubemodel");
+    *has_stats = convolving != 0;
+    return run_group_mom0(c, S, S.params, 1, S.chi2, d_cube, convolving != 0, c->stream);
   }
   if ((rc = run_model(c, S, S.params, 1, c->stream, true))) return rc;
   const double* iu = nullptr;
@@ -3672,12 +3686,47 @@ int slamhip_cubemodel(slamhip_ctx* c, const double* params, int convolving,
   hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, c->stream, k, S.partial, c->red_blocks,
                      (const unsigned char*)nullptr, S.stats, (double*)nullptr);
   hipLaunchKernelGGL(k_scale, dim3(1024), dim3(256), 0, c->stream, d_cube, (long long)ncube, S.stats);
+  HIP_TRY(c, hipGetLastError());
+  return SLAMHIP_OK;
+}
+
+int slamhip_cubemodel(slamhip_ctx* c, const double* params, int convolving,
+                      double* out, double* stats_out) {
+  int rc = single_prepare(c, params);
+  if (rc) return rc;
+  if (!out) return fail(c, SLAMHIP_ERR_ARG, "null output");
+  bool has_stats = false;
+  if ((rc = cube_on_device(c, convolving, &has_stats))) return rc;
+  const size_t ncube = (size_t)c->k.nv * c->k.ny * c->k.nx;
+  hipError_t e = hipMemcpyAsync(out, c->d_cube, ncube * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess && stats_out) {
+    if (has_stats) {
+      e = hipMemcpyAsync(stats_out, c->own.stats, 4 * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+    } else {
+      for (int i = 0; i < 4; ++i) stats_out[i] = std::numeric_limits<double>::quiet_NaN();
+    }
+  }
+  return single_finish(c, e, "cubemodel");
+}
+
+int slamhip_moments(slamhip_ctx* c, const double* params, double dv, double clip,
+                    double* mom0_out, double* mom1_out) {
+  int rc = single_prepare(c, params);
+  if (rc) return rc;
+  if (!mom0_out || !mom1_out) return fail(c, SLAMHIP_ERR_ARG, "null output");
+  bool has_stats = false;
+  if ((rc = cube_on_device(c, 1, &has_stats))) return rc;
+  const FitK& k = c->k;
+  const long long npix = (long long)k.ny * k.nx;
+  double* maps = c->d_cube + (size_t)k.nv * npix;
+  hipLaunchKernelGGL(k_moments, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, c->stream,
+                     c->d_cube, k.vpad, k.nv, npix, dv, clip, maps, maps + npix);
   hipError_t e = hipGetLastError();
   if (e == hipSuccess)
-    e = hipMemcpyAsync(out, d_cube, ncube * sizeof(double), hipMemcpyDeviceToHost, c->stream);
-  if (e == hipSuccess && stats_out)
-    e = hipMemcpyAsync(stats_out, S.stats, 4 * sizeof(double), hipMemcpyDeviceToHost, c->stream);
-  return single_finish(c, e, "cubemodel");
+    e = hipMemcpyAsync(mom0_out, maps, npix * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess)
+    e = hipMemcpyAsync(mom1_out, maps + npix, npix * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+  return single_finish(c, e, "moments");
 }
 
 // k_prep alone for one parameter vector, its WalkerK copied back.

@@ -209,6 +209,16 @@ class HipLikelihood:
             return out, dict(gf=st[0], ff=st[1], scale=st[2], chi2=st[3])
         return out
 
+    def moments(self, p, dv, clip):
+        """(mom0, mom1) [ny, nx] of the model cube for `p` over its channels:
+        mom0 = sum(d) dv, mom1 = sum(d v) / sum(d), NaN where mom0 < clip."""
+        a = self._params(p, False)
+        m0 = np.empty((self.ny, self.nx), dtype=np.float64)
+        m1 = np.empty((self.ny, self.nx), dtype=np.float64)
+        self._check(self._lib.slamhip_moments(
+            self._ctx, as_dp(a), float(dv), float(clip), as_dp(m0), as_dp(m1)), 'moments')
+        return m0, m1
+
     def iunif(self, p):
         a = self._params(p, False)
         out = np.empty((self.nv, self.nneed, self.nneed), dtype=np.float64)

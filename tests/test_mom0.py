@@ -164,3 +164,62 @@ def test_gpu_sparse_path_equals_dense_on_a_multi_segment_image():
             assert st['chi2'] == pytest.approx(chi2[i], rel=1e-12)
     finally:
         fit.close()
+
+
+# ---------------------------------------------------------------------------
+# Moment maps behind plotmom: golden vectors recorded from the
+# reference's makemom01 by tests/golden/make_golden_moments.py.
+def moments_gold():
+    return np.load(os.path.join(_golden.GOLDEN_DIR, 'channelfit_moments.npz'))
+
+
+@pytest.mark.parametrize('cfg', ['A', 'B'])
+def test_host_moment_maps_bitwise(cfg):
+    """makegrid's observed mom0 / mom1 and makemom01 on the reference's own
+    model cubes == the reference's maps, bit for bit (NaN pattern included)."""
+    from slam_amd.channelfit import makemom01
+    mg = moments_gold()
+    g = _golden.load(cfg)
+    fit = product_fit(cfg, 'uniform')
+    assert np.array_equal(fit.mom0, mg[f'{cfg}_obs_mom0'])
+    assert np.array_equal(fit.mom1, mg[f'{cfg}_obs_mom1'], equal_nan=True)
+    assert fit.sigma_mom0 == mg[f'{cfg}_sigma_mom0']
+    for n in (str(s) for s in mg[f'{cfg}_vector_names']):
+        if f'vec_{n}_model' not in g.files:
+            continue
+        m = makemom01(g[f'vec_{n}_model'], fit.v_valid, fit.sigma)
+        assert np.array_equal(m['mom0'], mg[f'{cfg}_vec_{n}_mom0'])
+        assert np.array_equal(m['mom1'], mg[f'{cfg}_vec_{n}_mom1'], equal_nan=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('cfg', ['A', 'B'])
+def test_gpu_moment_maps(cfg):
+    """slamhip_moments: bit-equal to numpy's reduction of the cube the GPU itself
+    returns (same order of additions), and equal to the reference's maps to the
+    cubes' own 1e-9 (pixels within 1e-9 of the 3 sigma_mom0 blanking threshold may
+    fall on either side of it)."""
+    from slam_amd.channelfit import PARAMKEYS as KEYS, makemom01
+    mg = moments_gold()
+    fit = product_fit(cfg, 'uniform')
+    clip = 3 * fit.sigma_mom0
+    for n in (str(s) for s in mg[f'{cfg}_vector_names']):
+        p = dict(zip(KEYS, mg[f'{cfg}_vec_{n}_p']))
+        mom0, mom1 = fit.modelmom('mod', **p)
+        own = makemom01(fit.cubemodel(**p), fit.v_valid, fit.sigma)
+        assert np.array_equal(mom0, own['mom0'])
+        assert np.array_equal(mom1, own['mom1'], equal_nan=True)
+        ref0, ref1 = mg[f'{cfg}_vec_{n}_mom0'], mg[f'{cfg}_vec_{n}_mom1']
+        assert _golden.relmax(mom0, ref0) < 1e-9
+        edge = np.abs(ref0 - clip) < 1e-9 * clip
+        assert np.array_equal(np.isnan(mom1) | edge, np.isnan(ref1) | edge)
+        both = np.isfinite(mom1) & np.isfinite(ref1)
+        assert both.sum() > 100
+        np.testing.assert_allclose(mom1[both], ref1[both], rtol=0, atol=1e-9)
+        # 'res' = observed - model, 'obs' = the maps makegrid kept
+        r0, r1 = fit.modelmom('res')
+        assert np.array_equal(r0, fit.mom0 - mom0)
+        assert np.array_equal(r1, fit.mom1 - mom1, equal_nan=True)
+        assert fit.modelmom('obs')[0] is fit.mom0
+    with pytest.raises(ValueError):
+        fit.modelmom('nothing')
