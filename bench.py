@@ -60,6 +60,10 @@ def main():
         print(_cpu_worker((args.config, args.bpa, args.scaling, args.cpu_worker, args.cpu_evals)))
         return
 
+    if os.environ.get('SLAM_BENCH_WATCHDOG'):     # a run that hangs says where, then ends
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ['SLAM_BENCH_WATCHDOG']), exit=True)
+
     multi = None
     if (int(os.environ.get('WORLD_SIZE', 1)) == 1 and args.cpu_evals > 0 and args.cpu_procs != 0
             and args.config != 'P5'):
@@ -113,7 +117,8 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt, startup_s], dtype=torch.float64, device='cuda')
+        t = torch.tensor([dt, startup_s], dtype=torch.float64,
+                         device='cpu' if args.backend == 'gloo' else 'cuda')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt, startup_s = float(t[0].item()), float(t[1].item())
     chi2 = chi2.cpu().numpy()
@@ -303,7 +308,7 @@ def run_pv(args, rank, world, torch, dist):
     barrier()
     kern = eng.profile_end()
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        t = torch.tensor([dt], dtype=torch.float64, device='cpu' if args.backend == 'gloo' else 'cuda')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     lnp = lnp.cpu().numpy()

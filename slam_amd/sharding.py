@@ -43,8 +43,13 @@ class ShardedLikelihood:
             else torch.device('cpu')
         if dist.is_available() and dist.is_initialized():
             self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+            # gloo is a host backend: its collectives get host tensors even when the
+            # likelihood runs on the GPU (all_gather_into_tensor on device tensors hangs there)
+            self.host_wire = self.on_gpu and dist.get_backend(group) == 'gloo'
         else:
             self.rank, self.world = 0, 1
+            self.host_wire = False
+        self.wire = torch.device('cpu') if self.host_wire else self.device
 
     def chi2(self, P, nw=None):
         torch, dist = self.torch, self.dist
@@ -53,11 +58,12 @@ class ShardedLikelihood:
         if self.rank == 0:
             Pt = torch.as_tensor(np.ascontiguousarray(P, dtype=np.float64)
                                  if not torch.is_tensor(P) else P,
-                                 dtype=torch.float64).to(self.device)
+                                 dtype=torch.float64).to(self.wire)
         else:
-            Pt = torch.empty((nw, self.nparam), dtype=torch.float64, device=self.device)
+            Pt = torch.empty((nw, self.nparam), dtype=torch.float64, device=self.wire)
         if self.world > 1:
             dist.broadcast(Pt, src=0, group=self.group)          # <= 13*8 B per walker
+        Pt = Pt.to(self.device)
         counts, offs = partition(nw, self.world)
         cnt, off = counts[self.rank], offs[self.rank]
         mine = Pt[off:off + cnt]
@@ -68,8 +74,9 @@ class ShardedLikelihood:
         if self.world == 1:
             return loc
         maxc = max(counts)
-        pad = torch.zeros(maxc, dtype=torch.float64, device=self.device)
+        pad = torch.zeros(maxc, dtype=torch.float64, device=self.wire)
         pad[:cnt] = loc
-        out = torch.empty(maxc * self.world, dtype=torch.float64, device=self.device)
+        out = torch.empty(maxc * self.world, dtype=torch.float64, device=self.wire)
         dist.all_gather_into_tensor(out, pad, group=self.group)   # 8 B per walker
-        return torch.cat([out[r * maxc:r * maxc + counts[r]] for r in range(self.world)])
+        out = torch.cat([out[r * maxc:r * maxc + counts[r]] for r in range(self.world)])
+        return out.to(self.device)

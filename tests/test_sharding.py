@@ -69,3 +69,52 @@ def test_single_process_passthrough():
     sh = ShardedLikelihood(fake_chi2, device='cpu')
     P = np.random.default_rng(1).random((5, 13))
     assert np.array_equal(sh.chi2(P).numpy(), fake_chi2(P))
+
+
+# ---------------------------------------------------------------------------
+# The real engine under two ranks (both on cuda:0, gloo between them): what a
+# node with fewer GPUs than ranks can rehearse of the N > 1 path.
+def _golden_fit():
+    import contextlib
+    import io
+
+    import _golden
+    from slam_amd.channelfit import ChannelFit
+    g = _golden.load('A')
+    kw = _golden.inputs(g)
+    fit = ChannelFit(disk=kw['disk'], envelope=kw['envelope'], progressbar=False)
+    fit.set_cube(kw['x'], kw['y'], kw['v'], kw['data'], kw['bmaj'], kw['bmin'], kw['bpa'], kw['sigma'])
+    with contextlib.redirect_stdout(io.StringIO()):
+        fit.makegrid(cubefits=None, pa=kw['pa'], incl=kw['incl'], rmax=kw['rmax'], vlim=kw['vlim'],
+                     nlayer=kw['nlayer'], gaussmargin=kw['gaussmargin'],
+                     signmajor=kw['signmajor'], signminor=kw['signminor'])
+    P = np.array([g[f'vec_{n}_p'] for n in _golden.vectors(g)])
+    return fit, np.concatenate([P, P[::-1], P[:3]])
+
+
+def _gpu_worker(rank, world, port, out_dir):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        fit, P = _golden_fit()
+        sh = ShardedLikelihood(fit.engine.chi2_batch_torch, device='cuda')
+        assert sh.host_wire
+        got = sh.chi2(P if rank == 0 else None, len(P))
+        assert got.is_cuda
+        np.save(os.path.join(out_dir, f'g{rank}.npy'), got.cpu().numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(300)
+def test_real_engine_two_ranks_equal_one(tmp_path):
+    fit, P = _golden_fit()
+    ref = fit.chi2_batch(P)
+    port = _free_port()
+    mp.spawn(_gpu_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        assert np.array_equal(np.load(tmp_path / f'g{r}.npy'), ref), r     # bitwise, on every rank
