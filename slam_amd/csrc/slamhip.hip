@@ -1173,7 +1173,30 @@ __device__ __forceinline__ void lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-template <int TY, int MAXR, bool DIRECT, int PITCH = 0, typename T = double>   // T: arithmetic type of tile and passes; PITCH: LDS tile pitch fixed at compile time (0: from kpad)
+// Row pass of one lane: C consecutive outputs res[c] += sum_u wx[u] row[c + u] over kpad
+// taps, the C-wide window of `row` rotating through registers (one LDS read per tap);
+// the taps come through the scalar cache (block-uniform address).  kpad is a multiple of RU.
+template <int C, int RU, typename T>
+__device__ __forceinline__ void row_taps(const T* row, const T* __restrict__ wx, int kpad, T* res) {
+  static_assert(RU % C == 0, "the window rotation must close over one unrolled step");
+  T win[C];
+#pragma unroll
+  for (int r = 0; r < C - 1; ++r) win[r] = row[r];
+  for (int u0 = 0; u0 < kpad; u0 += RU) {
+#pragma unroll
+    for (int qq = 0; qq < RU; ++qq) {
+      win[(qq + C - 1) % C] = row[u0 + qq + C - 1];
+      const T wgt = wx[u0 + qq];
+#pragma unroll
+      for (int r = 0; r < C; ++r) res[r] = fma(wgt, win[(r + qq) % C], res[r]);
+    }
+  }
+}
+
+// T: arithmetic type of tile and passes; PITCH: LDS tile pitch fixed at compile time (0: from
+// kpad); MULTI: the factorised beam may have several terms (false: exactly one, the column
+// pass's sums are then born after the row pass and cost it no registers)
+template <int TY, int MAXR, bool DIRECT, int PITCH = 0, typename T = double, bool MULTI = true>
 __global__ void __launch_bounds__(CV_NT, 4)
 k_conv_chi2(FitK g, const T* __restrict__ iunif,
             const int* __restrict__ cellx, const double* __restrict__ fracx,
@@ -1455,32 +1478,33 @@ k_conv_chi2(FitK g, const T* __restrict__ iunif,
         }
       }
     }
-    for (int rk = 0; !DIRECT && rk < nrank; ++rk) {
+    for (int rk = 0; !DIRECT && rk < (MULTI ? nrank : 1); ++rk) {
       // taps through the scalar cache (block-uniform addresses): the LDS is busy enough
       const T* __restrict__ wxr = fold_w ? gxw + (long long)wi * kpad : gxp + rk * kpad;
       const T* __restrict__ wyr = fold_w ? gyw + (long long)wi * kpad : gyp + rk * kpad;
+      // A group of up to 64 listed rows per step.  A lane takes one row and, of the wave's
+      // R output columns, all R when the group holds more than 32 rows, half of them when
+      // it holds 17..32 (lanes l and l + 32 share a row), a quarter when it holds fewer:
+      // a thin group costs a half or a quarter of a full one instead of idling its lanes.
       T res[MAXR][R];
+      // rows of group q, and the lanes-per-row shift (0 / 1 / 2); both block-uniform
+      auto group = [&](int q, int& m, int& sh) {
+        m = min(nlr - q * 64, 64);
+        sh = m > 32 ? 0 : m > 16 ? 1 : 2;
+      };
 #pragma unroll
       for (int q = 0; q < MAXR; ++q) {
-        const int ridx = q * 64 + lane;
 #pragma unroll
         for (int r = 0; r < R; ++r) res[q][r] = 0;
-        if (q * 64 < nlr && ridx < nlr) {
-          const int rr = s_rowlist[ridx];
-          const T* row = tile + rr * P + wv * R;
-          T win[R];
-#pragma unroll
-          for (int r = 0; r < R - 1; ++r) win[r] = row[r];
-          for (int u0 = 0; u0 < kpad; u0 += R) {
-#pragma unroll
-            for (int qq = 0; qq < R; ++qq) {
-              win[(qq + R - 1) % R] = row[u0 + qq + R - 1];
-              const T wgt = wxr[u0 + qq];
-#pragma unroll
-              for (int r = 0; r < R; ++r)
-                res[q][r] = fma(wgt, win[(r + qq) % R], res[q][r]);
-            }
-          }
+        int m, sh;
+        group(q, m, sh);
+        if (m <= 0) continue;
+        const int l = lane & (63 >> sh);
+        if (l < m) {
+          const T* row = tile + s_rowlist[q * 64 + l] * P + wv * R + (lane >> (6 - sh)) * (R >> sh);
+          if (sh == 0) row_taps<R, R>(row, wxr, kpad, res[q]);
+          else if (sh == 1) row_taps<R / 2, R>(row, wxr, kpad, res[q]);
+          else row_taps<R / 4, R>(row, wxr, kpad, res[q]);
         }
       }
       STAMP(3);
@@ -1499,11 +1523,15 @@ k_conv_chi2(FitK g, const T* __restrict__ iunif,
       }
 #pragma unroll
       for (int q = 0; q < MAXR; ++q) {
-        const int ridx = q * 64 + lane;
-        if (ridx < nlr) {
-          const int rr = s_rowlist[ridx];
+        int m, sh;
+        group(q, m, sh);
+        if (m <= 0) continue;
+        const int l = lane & (63 >> sh);
+        if (l < m) {
+          T* o = tmp + s_rowlist[q * 64 + l] * P2 + wv * R + (lane >> (6 - sh)) * (R >> sh);
 #pragma unroll
-          for (int r = 0; r < R; ++r) tmp[rr * P2 + wv * R + r] = res[q][r];
+          for (int r = 0; r < R; ++r)
+            if (r < (R >> sh)) o[r] = res[q][r];
         }
       }
       lds_barrier();
@@ -2955,7 +2983,11 @@ int run_group_mom0(slamhip_ctx* c, Scratch& S, const double* d_params, int nw, d
 // The fused kernel's instance for the context's tile variant, tap form and
 // arithmetic type T (its address for hipFuncSetAttribute, or a launch).
 template <typename T>
-const void* fused_instance(int variant, bool direct, bool fixed) {
+const void* fused_instance(int variant, bool direct, bool fixed, bool multi = true) {
+  if (!direct && !multi)
+    return variant == 0 ? (const void*)k_conv_chi2<64, 2, false, 0, T, false>
+         : variant == 1 ? (const void*)k_conv_chi2<64, 3, false, 0, T, false>
+                        : (const void*)k_conv_chi2<32, 2, false, 0, T, false>;
   if (!direct)
     return variant == 0 ? (const void*)k_conv_chi2<64, 2, false, 0, T>
          : variant == 1 ? (const void*)k_conv_chi2<64, 3, false, 0, T>
@@ -2971,21 +3003,26 @@ void launch_fused(slamhip_ctx* c, Scratch& S, int fz_rank, hipStream_t st, const
                   const T* ft, const T* gxw, const T* gyw) {
   dim3 gz(fz_rank ? c->persist_blocks : c->persist_direct, 1, 1);
   const size_t fz_lds = fz_rank ? c->fz_lds : c->fz_lds_direct;
-#define SLAM_FUSED(TY_, MR_, DIR_, PITCH_)                                                        \
-  hipLaunchKernelGGL((k_conv_chi2<TY_, MR_, DIR_, PITCH_, T>), gz, dim3(CV_NT), fz_lds, st, c->k, \
-                     (const T*)S.iunif, S.cellx, S.fracx, S.celly, S.fracy, S.livelist,           \
-                     S.livecount, (int)c->fz_grid.x, (int)c->fz_grid.y, S.partial, c->kpad,       \
+#define SLAM_FUSED_M(TY_, MR_, DIR_, PITCH_, MULTI_)                                               \
+  hipLaunchKernelGGL((k_conv_chi2<TY_, MR_, DIR_, PITCH_, T, MULTI_>), gz, dim3(CV_NT), fz_lds, st, \
+                     c->k, (const T*)S.iunif, S.cellx, S.fracx, S.celly, S.fracy, S.livelist,       \
+                     S.livecount, (int)c->fz_grid.x, (int)c->fz_grid.y, S.partial, c->kpad,         \
                      fz_rank, gx, gy, ft, gxw, gyw)
+#define SLAM_FUSED(TY_, MR_, DIR_, PITCH_) SLAM_FUSED_M(TY_, MR_, DIR_, PITCH_, true)
+#define SLAM_FUSED_SEP(TY_, MR_) \
+  do { if (fz_rank == 1) SLAM_FUSED_M(TY_, MR_, false, 0, false); else SLAM_FUSED(TY_, MR_, false, 0); } while (0)
   switch (c->fz_variant) {
     case 0:
-      if (fz_rank) SLAM_FUSED(64, 2, false, 0);
+      if (fz_rank) SLAM_FUSED_SEP(64, 2);
       else if (c->direct_fixed) SLAM_FUSED(64, 2, true, DIRECT_PITCH);
       else SLAM_FUSED(64, 2, true, 0);
       break;
-    case 1: if (fz_rank) SLAM_FUSED(64, 3, false, 0); else SLAM_FUSED(64, 3, true, 0); break;
-    default: if (fz_rank) SLAM_FUSED(32, 2, false, 0); else SLAM_FUSED(32, 2, true, 0); break;
+    case 1: if (fz_rank) SLAM_FUSED_SEP(64, 3); else SLAM_FUSED(64, 3, true, 0); break;
+    default: if (fz_rank) SLAM_FUSED_SEP(32, 2); else SLAM_FUSED(32, 2, true, 0); break;
   }
+#undef SLAM_FUSED_SEP
 #undef SLAM_FUSED
+#undef SLAM_FUSED_M
 }
 
 int run_group(slamhip_ctx* c, Scratch& S, const double* d_params, int nw, double* d_chi2,
@@ -3237,8 +3274,12 @@ int slamhip_create(const slamhip_desc* d, slamhip_ctx** out) {
                             : fused_instance<double>(c->fz_variant, false, false);
     const void* fd = c->f32 ? fused_instance<float>(c->fz_variant, true, c->direct_fixed)
                             : fused_instance<double>(c->fz_variant, true, c->direct_fixed);
-    if (c->nrank >= 1)
+    if (c->nrank >= 1) {
       HIP_TRY(c, hipFuncSetAttribute(fz, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->fz_lds));
+      const void* f1 = c->f32 ? fused_instance<float>(c->fz_variant, false, false, false)
+                              : fused_instance<double>(c->fz_variant, false, false, false);
+      HIP_TRY(c, hipFuncSetAttribute(f1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->fz_lds));
+    }
     if (direct_ok)
       HIP_TRY(c, hipFuncSetAttribute(fd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->fz_lds_direct));
   }
