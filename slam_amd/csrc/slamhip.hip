@@ -608,16 +608,18 @@ __device__ inline unsigned wave_or(unsigned v) {
 // headline workload about one triple in eight is listed.
 __global__ void __launch_bounds__(256)
 k_plan(FitK g, const WalkerK* __restrict__ wk, const float2* __restrict__ grange, int nw, int ntile,
-       uint2* __restrict__ items, int* __restrict__ nitems) {
+       uint4* __restrict__ items, int* __restrict__ nitems) {
   const int t = blockIdx.x * 256 + threadIdx.x;
   const int nchunk = g.nvpad / CH;
-  int wi = 0, tile = 0;
+  int wi = 0, tile = 0, goff = 0, nl = 0;
   float lo = 3.0e38f, hi = -3.0e38f;
   const bool live = t < nw * ntile;
   if (live) {
     wi = t / ntile;
     tile = t - wi * ntile;
-    const int g0 = g.tile_goff[tile] >> 6, ng = g.tile_nl[tile] * 4;
+    goff = g.tile_goff[tile];
+    nl = g.tile_nl[tile];
+    const int g0 = goff >> 6, ng = nl * 4;
     const float2* r = grange + (long long)wi * (g.nslot >> 6) + g0;
     for (int q = 0; q < ng; ++q) {
       const float2 v = r[q];
@@ -653,7 +655,7 @@ k_plan(FitK g, const WalkerK* __restrict__ wk, const float2* __restrict__ grange
       const double cmid = 0.5 * (g.ch_vmin[cix] + g.ch_vmax[cix]);
       const double hwc = hw + 0.5 * (g.ch_vmax[cix] - g.ch_vmin[cix]);
       if (((double)lo + voff <= cmid + hwc) && ((double)hi + voff >= cmid - hwc))
-        items[base++] = make_uint2((unsigned)(wi * ntile + tile), (unsigned)cix);
+        items[base++] = make_uint4((unsigned)(wi * ntile + tile), (unsigned)cix, (unsigned)goff, (unsigned)nl);
     }
   }
 }
@@ -667,7 +669,7 @@ __global__ void __launch_bounds__(256)
 k_profile(FitK g, const WalkerK* __restrict__ wk, const typename Real<TG>::vec2* __restrict__ geom,
           const unsigned* __restrict__ gflag, T* __restrict__ iunif, unsigned char* __restrict__ flags, int ftx, int fty,
           unsigned char* __restrict__ winflag, int wnx, int wny, int wsx, int wsy,
-          const uint2* __restrict__ items, const int* __restrict__ nitems) {
+          const uint4* __restrict__ items, const int* __restrict__ nitems) {
   using T2 = typename Real<TG>::vec2;
   // double geometry: the reference's table entry, bit for bit (lanes near a table
   // boundary redo the index in the reference's operation order); float geometry
@@ -684,8 +686,12 @@ k_profile(FitK g, const WalkerK* __restrict__ wk, const typename Real<TG>::vec2*
   const int per_xcd = (nit + 7) >> 3;
   const int it = (int)(blockIdx.x & 7u) * per_xcd + (int)(blockIdx.x >> 3);
   if ((int)(blockIdx.x >> 3) >= per_xcd || it >= nit) return;
-  const uint2 item = items[it];                           // block-uniform: kept in SGPRs, so that
+  // the item carries its tile's first slot and rank count, so that the flag words and
+  // the first rank's entries can be asked for at once (no table lookup in between)
+  const uint4 item = items[it];                           // block-uniform: kept in SGPRs, so that
   const unsigned ixw = __builtin_amdgcn_readfirstlane(item.x);   // everything indexed by it is scalar too
+  const int goff = (int)__builtin_amdgcn_readfirstlane(item.z);
+  const int nl = (int)__builtin_amdgcn_readfirstlane(item.w);
   const int ntile = ftx * fty;
   const int wi = (int)(ixw / (unsigned)ntile);
   const int tile = (int)(ixw - (unsigned)wi * (unsigned)ntile);
@@ -700,18 +706,23 @@ k_profile(FitK g, const WalkerK* __restrict__ wk, const typename Real<TG>::vec2*
   const int y = tby * PT_Y + tid / PT_X;
   const bool inb = x < n && y < n;
   const int pix = inb ? y * n + x : 0;
-  const int nl = g.tile_nl[tile];
   const int nsurf = w.nsurf;
   const double rinv = w.rinv, hw = w.halfwidth, voff = w.voff;
   // this thread's first slot; rank i of surface s is at gw[s*nslot + i*256]
-  const T2* gw = geom + (long long)wi * 4 * g.nslot + g.tile_goff[tile] + tid;
+  const T2* gw = geom + (long long)wi * 4 * g.nslot + goff + tid;
   const long long ftile = ntile;
   unsigned char* fl = flags + (long long)wi * g.nv * ftile + tile;
   // k_surface's flag word of this wave's 64 samples of a rank: bit s = surface s
   // was stored (else every entry adds nothing and nothing is read).  The first
   // two are requested here, under the table's round trip.
-  const unsigned* gf = gflag + (long long)wi * (g.nslot >> 6) + (g.tile_goff[tile] >> 6) + (tid >> 6);
+  const unsigned* gf = gflag + (long long)wi * (g.nslot >> 6) + (goff >> 6) + (tid >> 6);
   const unsigned f0v = nl > 0 ? gf[0] : 0u, f1v = nl > 1 ? gf[4] : 0u;
+  // the first rank's entries, asked for before its flag word is known (a surface that was
+  // not stored holds stale bytes there: dropped below)
+  T2 spec[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+    spec[s] = nl > 0 ? gw[(long long)s * g.nslot] : Real<TG>::make2(Real<TG>::masked, (TG)0);
 
   __syncthreads();                                        // s_prof ready
   {
@@ -793,7 +804,7 @@ k_profile(FitK g, const WalkerK* __restrict__ wk, const typename Real<TG>::vec2*
     T2 q[4], qn[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s)
-      qn[s] = ((fnxt >> s) & 1u) ? gw[(long long)s * g.nslot] : Real<TG>::make2(Real<TG>::masked, (TG)0);
+      qn[s] = ((fnxt >> s) & 1u) ? spec[s] : Real<TG>::make2(Real<TG>::masked, (TG)0);
     for (int i = 0; i < nl; ++i) {
 #pragma unroll
       for (int s = 0; s < 4; ++s) q[s] = qn[s];
@@ -2462,7 +2473,7 @@ struct Scratch {
   void* geom = nullptr;        // [walker][surface][sample] {vlos*sqrt(M), weight} as double2 or float2
   unsigned* gflag = nullptr;   // [walker][sample / 64] bit s: surface s of these 64 samples was stored
   float2* grange = nullptr;    // [walker][sample / 64] range of the stored vlos*sqrt(M) of these 64 samples
-  uint2* items = nullptr;      // k_plan's list: (walker * tiles + tile, channel block) that can hold emission
+  uint4* items = nullptr;      // k_plan's list: (walker * tiles + tile, channel block) that can hold emission
   void* iunif = nullptr;       // [walker][nv][nneed][nneed], double or float
   double* partial = nullptr;
   double* stats = nullptr;
@@ -2648,7 +2659,7 @@ size_t carve(const slamhip_ctx* c, size_t W, unsigned char* base, Scratch* s) {
   t.geom = take(W * 4 * (size_t)k.nslot * 2 * c->gitem);
   t.gflag = reinterpret_cast<unsigned*>(take(W * (size_t)(k.nslot / 64) * sizeof(unsigned)));
   t.grange = reinterpret_cast<float2*>(take(W * (size_t)(k.nslot / 64) * sizeof(float2)));
-  t.items = reinterpret_cast<uint2*>(take(W * (size_t)c->ftx * c->fty * (k.nvpad / CH) * sizeof(uint2)));
+  t.items = reinterpret_cast<uint4*>(take(W * (size_t)c->ftx * c->fty * (k.nvpad / CH) * sizeof(uint4)));
   t.iunif = take(W * k.nv * n * n * c->item);
   t.partial = reinterpret_cast<double*>(take(W * c->max_blocks * 3 * sizeof(double)));
   t.stats = reinterpret_cast<double*>(take(W * 6 * sizeof(double)));
