@@ -797,8 +797,10 @@ k_profile(FitK g, const WalkerK* __restrict__ wk, const typename Real<TG>::vec2*
     };
     // Flags run two ranks ahead of the work, entries one (the word for rank i+2
     // stays in a VGPR until it is needed: moving it to an SGPR at once would
-    // wait for the load).  (Walking only the stored (rank, surface) pairs with four
-    // loads in flight was tried: 29.8 instead of 28.2 us/eval.)
+    // wait for the load).  Tried and not kept: walking only the stored (rank, surface)
+    // pairs with four loads in flight (29.8 instead of 28.2 us/eval); entries two ranks
+    // ahead in three register sets that trade places, every rank issuing the same four
+    // loads (139 VGPRs, 3 waves per SIMD: 31.0 us/eval).
     unsigned fcur = 0, fnxt = __builtin_amdgcn_readfirstlane(f0v);
     unsigned fnn = f1v;
     T2 q[4], qn[4];
@@ -864,6 +866,27 @@ __device__ inline double wave_sum(double v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
   return v;
+}
+
+// Sum over the wave in the VALU's data-parallel-primitive network, no LDS round trips:
+// butterflies within each row of 16 lanes (every lane then holds its row's sum), row 0
+// into row 1 and row 2 into row 3, rows 0+1 into row 3.  Returns the total in every lane.
+template <int CTRL, int ROWS>
+__device__ __forceinline__ double dpp_add(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROWS, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROWS, 0xf, false);
+  return v + __hiloint2double(hi, lo);                   // lanes outside ROWS add +0
+}
+__device__ __forceinline__ double wave_sum_dpp(double v) {
+  v = dpp_add<0xB1, 0xf>(v);                             // quad_perm [1,0,3,2]
+  v = dpp_add<0x4E, 0xf>(v);                             // quad_perm [2,3,0,1]
+  v = dpp_add<0x124, 0xf>(v);                            // row_ror:4
+  v = dpp_add<0x128, 0xf>(v);                            // row_ror:8
+  v = dpp_add<0x142, 0xa>(v);                            // row_bcast:15 into rows 1 and 3
+  v = dpp_add<0x143, 0xc>(v);                            // row_bcast:31 into rows 2 and 3
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+  return __hiloint2double(hi, lo);
 }
 
 template <int TY>
@@ -1656,8 +1679,8 @@ k_conv_chi2(FitK g, const T* __restrict__ iunif,
         }
       }
     }
-    gf = wave_sum(gf);
-    ff = wave_sum(ff);
+    gf = wave_sum_dpp(gf);
+    ff = wave_sum_dpp(ff);
     if (lane == 0) { sg[wv] = gf; sf[wv] = ff; }
     if (tid < DW) s_desc[par ^ 1][tid] = nextw;
     if (tid == 0) s_ticket = fut;
