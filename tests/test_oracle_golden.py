@@ -90,3 +90,15 @@ def test_known_answer():
     c = orc.chi2_of(s, p)
     assert float(k['chi2']) == 4229.974367626359
     np.testing.assert_allclose(c, 4229.974367626359, rtol=1e-13)
+
+
+def test_channel_chunks_change_nothing(case):
+    """`kchunk` (the oracle evaluating the cube a few channels at a time, which is how the
+    full-size config-4 GPU test affords it) gives the unchunked model bit for bit."""
+    g, s = case
+    name = _golden.vectors(g)[0]
+    p = g[f'vec_{name}_p']
+    whole = orc.cubemodel(s, p)
+    for kc in (1, 3):
+        np.testing.assert_array_equal(orc.cubemodel(s, p, kchunk=kc), whole)
+    assert orc.chi2_of(s, p, kchunk=2) == orc.chi2_of(s, p)
