@@ -103,7 +103,12 @@ int slampv_lnprob_batch(slampv_ctx* ctx, const double* params, int nw,
 
 /* Same with `params_dev` [nw][6] and `lnp_dev` [nw] resident on the context's
  * GPU; enqueued on `stream` (hipStream_t as void*, NULL = default) and NOT
- * waited for. */
+ * waited for.  Every call on a context works in that context's one scratch
+ * set: a call enqueued on another stream than the previous call first waits
+ * (event) for the previous call's last kernel, so calls on one context are
+ * ordered and never run concurrently; calls from several host threads on one
+ * context must be serialised by the caller.  For concurrency use one context
+ * per stream. */
 int slampv_lnprob_batch_dev(slampv_ctx* ctx, const double* params_dev, int nw,
                             double* lnp_dev, void* stream);
 

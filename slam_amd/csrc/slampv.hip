@@ -586,6 +586,11 @@ struct slampv_ctx {
   int* d_order = nullptr;
   size_t lds_tau = 0, lds_nest = 0, lds_cut = 0;
   hipStream_t stream = nullptr;
+  // Every launch group runs in the context's one scratch set: a group on another stream
+  // than the previous one first waits for that one's last kernel.
+  hipEvent_t done = nullptr;
+  hipStream_t last = nullptr;
+  bool used = false;
   bool profiling = false;
   struct Span { int kid; hipEvent_t a, b; };
   std::vector<Span> spans;
@@ -689,6 +694,8 @@ int check_desc(slampv_ctx* c, const slampv_desc* d) {
 int run_group(slampv_ctx* c, const double* d_params, int nw, double* d_lnp, double* d_stats,
               hipStream_t st) {
   const PvK& k = c->k;
+  if (!c->done) HIP_TRY(c, hipEventCreateWithFlags(&c->done, hipEventDisableTiming));
+  if (c->used && c->last != st) HIP_TRY(c, hipStreamWaitEvent(st, c->done, 0));
   {
     Timed t(c, PK_PREP, st);
     hipLaunchKernelGGL(k_pv_prep, dim3((nw + 63) / 64), dim3(64), 0, st, k, d_params, nw, c->d_wk,
@@ -727,6 +734,9 @@ int run_group(slampv_ctx* c, const double* d_params, int nw, double* d_lnp, doub
                        c->d_tmax, d_lnp, d_stats);
   }
   HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipEventRecord(c->done, st));
+  c->last = st;
+  c->used = true;
   return SLAMPV_OK;
 }
 
@@ -758,6 +768,7 @@ void slampv_destroy(slampv_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipDeviceSynchronize();
   for (auto& s : ctx->spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
+  if (ctx->done) (void)hipEventDestroy(ctx->done);
   for (void* p : ctx->allocs) (void)hipFree(p);
   delete ctx;
 }

@@ -138,7 +138,10 @@ class PVEngine:
         return out
 
     def lnprob_batch_torch(self, Q, out=None, stream=None):
-        """Same for a float64 CUDA tensor Q[nw, 6]; enqueued, not synchronised."""
+        """Same for a float64 CUDA tensor Q[nw, 6]; enqueued on `stream` (default:
+        torch's current stream), not synchronised.  Calls on one engine share its scratch
+        set: the library orders a call behind the previous one when their streams differ
+        (they never overlap); use one engine per stream for concurrency."""
         import torch
         if not (Q.is_cuda and Q.dtype == torch.float64 and Q.dim() == 2
                 and Q.shape[1] == _pvlib.NPARAM):

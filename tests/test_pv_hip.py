@@ -282,6 +282,38 @@ def test_torch_device_entry():
     assert np.array_equal(dev.cpu().numpy(), host)
 
 
+def test_calls_on_different_streams_are_ordered():
+    """Every launch group of a context works in its one scratch set: a batch enqueued on a
+    side stream and not waited for, followed at once by a host batch on the context's own
+    stream, must give the serial results (the later call waits on the earlier one's event)."""
+    import torch
+    f = gold('S3')
+    kw = call_kw(f)
+    rng = np.random.default_rng(9)
+    obs = rng.normal(0, 1, (2, len(f['in_v']), len(f['in_x'])))
+    m = model_from(f)
+    m.set_observations(obs[0], obs[1], 0.5, 2.0)
+    n = 96
+    Q = np.column_stack([rng.uniform(0.1, 1, n), np.r_[70., rng.uniform(20, 150, n - 1)],
+                         rng.uniform(0, 1, n), 10**rng.uniform(-1, 2, n),
+                         10**rng.uniform(0, 3, n), rng.uniform(0, 5, n)])
+    ref = m.lnprob_batch(Q, kw['incl'], None, 1., kw['rout'])
+    eng = m.engine(70., kw['incl'], None, 1., kw['rout'])
+    Qd = torch.tensor(Q, device='cuda')
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    for _ in range(3):
+        with torch.cuda.stream(side):
+            out1 = eng.lnprob_batch_torch(Qd)             # side stream, not waited for
+        got2 = eng.lnprob_batch(Q[::-1])                  # context stream, at once
+        with torch.cuda.stream(side):
+            out3 = eng.lnprob_batch_torch(Qd)
+        side.synchronize()
+        assert np.array_equal(out1.cpu().numpy(), ref)
+        assert np.array_equal(got2, ref[::-1])
+        assert np.array_equal(out3.cpu().numpy(), ref)
+
+
 def test_all_zero_model_gives_zero_lnprob():
     """Everything masked out (rout below every cell): the reference's model is
     NaN everywhere and its nansum-based lnprob is 0."""
