@@ -56,6 +56,7 @@ constexpr double IDX_BIAS = (22.5 + IDX_OFF) * IDX_SCALE + IDX_FGUARD + 45035996
 constexpr int IDX_HI0 = 0x43300000 + IDX_OFF;         // high word of the sum for floor(t) = 0
 constexpr int MAX_RANK = 24;                 // beam outer-product terms the fused kernel accepts
 constexpr unsigned LEAF_PAD = 0xffffffffu;    // slot without a sample
+constexpr int SEP_PITCH = (CONV_TX + 32) | 1;          // fused factorised beam, kpad == 32: the pitch fz_tile_bytes gives, fixed at compile time
 constexpr int DIRECT_PITCH = (CONV_TX + 32) | 1;       // fused direct taps, kpad <= 32: LDS tile pitch (room for the staging's column shift)
 constexpr int DIRECT_MIN_RANK = 6;           // beams needing this many terms or more get direct taps in the fused kernel
 constexpr int PREP_TILES = 1024;             // conv windows per axis pair k_prep can index (ntx + nty)
@@ -1415,7 +1416,22 @@ k_conv_chi2(FitK g, const T* __restrict__ iunif,
         s_rowlist[pos] = (unsigned char)tid;
       }
     }
-    {
+    if constexpr (PITCH != 0 && !DIRECT && MAXR == 2) {
+      // Fixed pitch: wave <-> rows wv, wv + 8, ..., a lane <-> one pair of columns.  The row
+      // masks shifted by wv once; bit 8j is then row wv + 8j, every row offset an immediate.
+      static_assert(TY + 31 <= 128, "two mask words cover the window's rows");
+      const unsigned long long z0 = m0 >> wv, z1 = m1 >> wv;
+      T* zp = lds + wv * P + lane * 2;
+      const bool pair = lane * 2 + 1 < P, last = lane * 2 + 1 == P;
+      constexpr int NJ = (TY + 31 + CV_NW - 1) / CV_NW;     // kpad <= 32
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const bool lit = j < 8 ? ((z0 >> (8 * j)) & 1ull) : ((z1 >> (8 * (j - 8))) & 1ull);   // wave-uniform; rows past the window are never lit
+        if (!lit) continue;
+        if (pair) { zp[j * CV_NW * P] = 0; zp[j * CV_NW * P + 1] = 0; }
+        else if (last) zp[j * CV_NW * P] = 0;
+      }
+    } else {
       // wave <-> rows, lanes <-> columns; only rows the row pass will read
       for (int rr = wv; rr < rows; rr += CV_NW) {
         const unsigned long long mw = rr < 64 ? m0 : rr < 128 ? m1 : rr < 192 ? m2 : m3;
@@ -2577,6 +2593,7 @@ struct slamhip_ctx {
   int fz_rank = 1;         // what the fused kernel uses in conv mode 0: nrank, or 0 = direct taps
   size_t fz_lds_direct = 0;
   bool direct_fixed = false;   // direct taps run the fixed-pitch instance
+  bool sep_fixed = false;      // one-term factorised beam with kpad == 32 runs its fixed-pitch instance
   int persist_direct = 1;
   size_t sep_lds = 0, c2d_lds = 0, fz_lds = 0;
   hipStream_t stream = nullptr;
@@ -3018,6 +3035,7 @@ int run_group_mom0(slamhip_ctx* c, Scratch& S, const double* d_params, int nw, d
 // arithmetic type T (its address for hipFuncSetAttribute, or a launch).
 template <typename T>
 const void* fused_instance(int variant, bool direct, bool fixed, bool multi = true) {
+  if (!direct && !multi && fixed) return (const void*)k_conv_chi2<64, 2, false, SEP_PITCH, T, false>;
   if (!direct && !multi)
     return variant == 0 ? (const void*)k_conv_chi2<64, 2, false, 0, T, false>
          : variant == 1 ? (const void*)k_conv_chi2<64, 3, false, 0, T, false>
@@ -3047,7 +3065,8 @@ void launch_fused(slamhip_ctx* c, Scratch& S, int fz_rank, hipStream_t st, const
   do { if (fz_rank == 1) SLAM_FUSED_M(TY_, MR_, false, 0, false); else SLAM_FUSED(TY_, MR_, false, 0); } while (0)
   switch (c->fz_variant) {
     case 0:
-      if (fz_rank) SLAM_FUSED_SEP(64, 2);
+      if (fz_rank == 1 && c->sep_fixed) SLAM_FUSED_M(64, 2, false, SEP_PITCH, false);
+      else if (fz_rank) SLAM_FUSED_SEP(64, 2);
       else if (c->direct_fixed) SLAM_FUSED(64, 2, true, DIRECT_PITCH);
       else SLAM_FUSED(64, 2, true, 0);
       break;
@@ -3308,6 +3327,11 @@ int slamhip_create(const slamhip_desc* d, slamhip_ctx** out) {
                             : fused_instance<double>(c->fz_variant, false, false);
     const void* fd = c->f32 ? fused_instance<float>(c->fz_variant, true, c->direct_fixed)
                             : fused_instance<double>(c->fz_variant, true, c->direct_fixed);
+    c->sep_fixed = c->fz_variant == 0 && c->kpad == 32;
+    if (c->nrank >= 1 && c->sep_fixed) {
+      const void* f2 = c->f32 ? fused_instance<float>(0, false, true, false) : fused_instance<double>(0, false, true, false);
+      HIP_TRY(c, hipFuncSetAttribute(f2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->fz_lds));
+    }
     if (c->nrank >= 1) {
       HIP_TRY(c, hipFuncSetAttribute(fz, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->fz_lds));
       const void* f1 = c->f32 ? fused_instance<float>(c->fz_variant, false, false, false)
