@@ -1237,10 +1237,12 @@ k_conv_chi2(FitK g, const T* __restrict__ iunif,
             const int* __restrict__ cellx, const double* __restrict__ fracx,
             const int* __restrict__ celly, const double* __restrict__ fracy,
             const WinDesc* __restrict__ list, int* __restrict__ count, int wnx, int wny,
-            double* __restrict__ partial, int kpad, int nrank,
+            double* __restrict__ partial, int kpad_arg, int nrank,
             const T* __restrict__ gxp, const T* __restrict__ gyp,
             const T* __restrict__ gbt,
             const T* __restrict__ gxw, const T* __restrict__ gyw) {
+  // the fixed-pitch factorised instance is only launched with 32 padded taps
+  const int kpad = (PITCH != 0 && !DIRECT) ? 32 : kpad_arg;
   // DIRECT (nrank == 0): the beam is not worth factorising (a rotated Gaussian
   // needs ~14 terms): direct K x K taps on the staged tile instead of row +
   // column passes
