@@ -1064,7 +1064,7 @@ struct __attribute__((aligned(16))) WinDesc {
   int e;                         // window id: (walker*nv + channel)*wnx*wny + by*wnx + bx
   int ixa, ixb, jya, jyb;        // observed pixel ranges whose cells it owns
   int nocc;                      // occupied 32x8 input tiles under the window
-  int z, tb;                     // plane walker*nv + channel; window column | row << 16 (spares the kernel's divisions)
+  int z, tb;                     // plane walker*nv + channel; window column | row << 8 | walker (of the group) << 16 (spares the kernel's divisions)
   unsigned long long rowmask[4]; // window rows that hold emission
   unsigned short ids[WIN_IDS];   // the first WIN_IDS occupied tiles (fy << 8 | fx)
   unsigned long long occ[FLAG_MAX / 64];   // all of them, as a bitmap
@@ -1180,7 +1180,7 @@ k_compact(FitK g, const unsigned char* __restrict__ winflag, int total,
   }
   D->nocc = nocc;
   D->z = z;
-  D->tb = tbx | (tby << 16);
+  D->tb = tbx | (tby << 8) | (wi << 16);
 #pragma unroll
   for (int q = 0; q < 4; ++q) D->rowmask[q] = rowm[q];
 #pragma unroll
@@ -1318,8 +1318,8 @@ k_conv_chi2(FitK g, const T* __restrict__ iunif,
     const int e = head(0);
     const int z = head(6);
     const int tb = head(7);
-    const int tby = tb >> 16, tbx = tb & 0xffff;
-    const int wi = z / g.nv, k = z - wi * g.nv;
+    const int tby = (tb >> 8) & 0xff, tbx = tb & 0xff;
+    const int wi = (int)((unsigned)tb >> 16), k = z - wi * g.nv;
     const T* src = iunif + (long long)z * n * n;
     const int x0 = tbx * (TX - 1), y0 = tby * (TY - 1);
     const int wx0 = x0 - ng, wy0 = y0 - ng;                 // window origin (image coords)
@@ -1348,15 +1348,22 @@ k_conv_chi2(FitK g, const T* __restrict__ iunif,
     const int prow = lane >> 3, pcol = (lane & 7) * 2;
     // position of tile (fyy, fxx) for this lane: LDS offset of its first pair, or -1;
     // bit 0 / 1 of `ok`: first / second pair inside the window
+    // Everything that depends on the tile and the window only is scalar; the lane adds its
+    // row / column within the tile and tests them against [lo, lo + span) ranges (one
+    // subtraction and one unsigned compare each).
+    const int lane_gofs = prow * n + pcol, lane_lofs = prow * P + pcol;
     auto tile_pos = [&](int fyy, int fxx, int& gofs, int& ok) {
-      const int gy = (fty0 + fyy) * PT_Y + prow;
-      const int gx = (ftx0 + fxx) * PT_X + pcol;
-      const int rr = gy - wy0, cc = gx - wx0;
-      const bool rowok = gy < n && rr >= 0 && rr < vrows;
-      ok = (rowok && gx < n && cc >= -woff && cc < vcols ? 1 : 0) |
-           (rowok && gx + 16 < n && cc + 16 >= -woff && cc + 16 < vcols ? 2 : 0);
-      gofs = gy * n + gx;
-      return rr * P + cc;
+      const int sgy = (fty0 + fyy) * PT_Y, sgx = (ftx0 + fxx) * PT_X;      // tile origin (image)
+      const int srr = sgy - wy0, scc = sgx - wx0;                          // ... in the window
+      const int rlo = max(-srr, 0), rspan = max(min(n - sgy, vrows - srr) - rlo, 0);
+      const int chi = min(n - sgx, vcols - scc);
+      const int c1lo = max(-woff - scc, 0), c1span = max(chi - c1lo, 0);
+      const int c2lo = max(-woff - scc - 16, 0), c2span = max(chi - 16 - c2lo, 0);
+      const bool rowok = (unsigned)(prow - rlo) < (unsigned)rspan;
+      ok = (rowok && (unsigned)(pcol - c1lo) < (unsigned)c1span ? 1 : 0) |
+           (rowok && (unsigned)(pcol - c2lo) < (unsigned)c2span ? 2 : 0);
+      gofs = sgy * n + sgx + lane_gofs;
+      return srr * P + scc + lane_lofs;
     };
     T2 sa[NSB], sb[NSB];
     int sofs[NSB], sok[NSB];
@@ -3348,6 +3355,8 @@ int slamhip_create(const slamhip_desc* d, slamhip_ctx** out) {
     c->fz_sx = CONV_TX - 1;
     c->fz_sy = (int)fz_ty - 1;
     c->fz_grid = dim3((n - 1 + c->fz_sx - 1) / c->fz_sx, (n - 1 + c->fz_sy - 1) / c->fz_sy, k.nv);
+    // the window descriptor packs column, row and walker into one word (8, 8 and 16 bits)
+    if (c->fz_grid.x > 255 || c->fz_grid.y > 255) c->fused = false;
   }
   if (c->c2d_lds > 48 * 1024 && c->c2d_lds <= 160 * 1024) {
     HIP_TRY(c, hipFuncSetAttribute((const void*)k_conv_2d,
