@@ -1389,14 +1389,18 @@ k_conv_chi2(FitK g, const T* __restrict__ iunif,
 #pragma unroll
     for (int r = 0; r < R; ++r) fdv[r] = 0.0;
     if (fold_w && wv < TY / R) {
+      // this wave's cell rows wv*R .. wv*R + 7 against the window's valid range [ya, yb);
+      // the observed row of the first one, then one row pitch up or down per cell row
       const int ya = (fyw >> 8) & 255, yb = (fyw >> 16) & 255;
+      const int rlo = max(ya - wv * R, 0), rhi = min(yb - wv * R, R);
+      if (rhi > rlo) fvalid = ((1u << rhi) - 1u) & ~((1u << rlo) - 1u);
+      const long long step = (fyw & 1) ? (long long)g.nx : -(long long)g.nx;
+      const double* rowp = dat + (long long)(head(3) + ((fyw & 1) ? wv * R : -(wv * R))) * g.nx;
+      if (pixx >= 0) {
 #pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const int cy = wv * R + r;                          // wave-uniform
-        if (cy >= ya && cy < yb) {
-          fvalid |= 1u << r;
-          const int jy = head(3) + ((fyw & 1) ? cy : -cy);
-          if (pixx >= 0) fdv[r] = dat[(long long)jy * g.nx + pixx];
+        for (int r = 0; r < R; ++r) {
+          if ((fvalid >> r) & 1u) fdv[r] = rowp[pixx];      // wave-uniform test
+          rowp += step;
         }
       }
     }
@@ -1598,11 +1602,18 @@ k_conv_chi2(FitK g, const T* __restrict__ iunif,
 
       if (wv < TY / R) {
         const T* col = tmp + (wv * R) * P2 + lane;
+        // fixed instance: the row masks from this wave's first row on, shifted once per window
+        // (rows wv*R .. wv*R + 63 cover every tap block of a 32-tap beam)
+        unsigned long long mcol = 0ull;
+        if constexpr (PITCH != 0 && MAXR == 2)
+          mcol = wv ? (m0 >> (wv * R)) | (m1 << (64 - wv * R)) : m0;
         for (int u0 = 0; u0 < kpad; u0 += R) {
           // rows wv*R+u0 .. +2R-2 feed this tap block: skip it if none holds emission
           const int ra = wv * R + u0;
           unsigned long long bits = 0ull;
-          {
+          if constexpr (PITCH != 0 && MAXR == 2) {
+            bits = mcol >> u0;
+          } else {
             const int w0 = ra >> 6, sh = ra & 63;
             const unsigned long long lo = w0 == 0 ? m0 : w0 == 1 ? m1 : w0 == 2 ? m2 : m3;
             const unsigned long long hi = w0 == 0 ? m1 : w0 == 1 ? m2 : w0 == 2 ? m3 : 0ull;
