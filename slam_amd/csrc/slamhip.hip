@@ -1444,6 +1444,23 @@ k_conv_chi2(FitK g, const T* __restrict__ iunif,
         if (pair) { zp[j * CV_NW * P] = 0; zp[j * CV_NW * P + 1] = 0; }
         else if (last) zp[j * CV_NW * P] = 0;
       }
+    } else if constexpr (!DIRECT && MAXR == 2) {
+      // Any pitch, rows < 128: this wave's rows wv, wv + 8, ... as one bit each (bit j of a
+      // byte-strided gather of the two mask words), then only the lit ones are visited.
+      const unsigned long long every8 = 0x0101010101010101ull;
+      unsigned long long g0 = (m0 >> wv) & every8, g1 = (m1 >> wv) & every8;   // bit 8j: row wv + 8j (+64)
+      T* zp = lds + wv * P;
+      for (int half = 0; half < 2; ++half) {
+        unsigned long long gb = half ? g1 : g0;
+        while (gb) {                                       // wave-uniform
+          const int j8 = __builtin_ctzll(gb);              // 8j
+          gb &= gb - 1;
+          T* rowp = zp + (half * 64 + j8) * P;
+          for (int c2 = lane * 2; c2 < P; c2 += 128) {
+            if (c2 + 1 < P) { rowp[c2] = 0; rowp[c2 + 1] = 0; } else rowp[c2] = 0;
+          }
+        }
+      }
     } else {
       // wave <-> rows, lanes <-> columns; only rows the row pass will read
       for (int rr = wv; rr < rows; rr += CV_NW) {
@@ -1604,15 +1621,22 @@ k_conv_chi2(FitK g, const T* __restrict__ iunif,
         const T* col = tmp + (wv * R) * P2 + lane;
         // fixed instance: the row masks from this wave's first row on, shifted once per window
         // (rows wv*R .. wv*R + 63 cover every tap block of a 32-tap beam)
-        unsigned long long mcol = 0ull;
-        if constexpr (PITCH != 0 && MAXR == 2)
+        unsigned long long mcol = 0ull, mcol_hi = 0ull;
+        if constexpr (MAXR == 2) {
           mcol = wv ? (m0 >> (wv * R)) | (m1 << (64 - wv * R)) : m0;
+          mcol_hi = m1 >> (wv * R);
+        }
         for (int u0 = 0; u0 < kpad; u0 += R) {
           // rows wv*R+u0 .. +2R-2 feed this tap block: skip it if none holds emission
           const int ra = wv * R + u0;
           unsigned long long bits = 0ull;
           if constexpr (PITCH != 0 && MAXR == 2) {
             bits = mcol >> u0;
+          } else if constexpr (MAXR == 2) {
+            // any tap count, rows < 128: the 128-bit mask slides down one tap block per trip
+            bits = mcol;
+            mcol = (mcol >> R) | (mcol_hi << (64 - R));
+            mcol_hi >>= R;
           } else {
             const int w0 = ra >> 6, sh = ra & 63;
             const unsigned long long lo = w0 == 0 ? m0 : w0 == 1 ? m1 : w0 == 2 ? m2 : m3;
