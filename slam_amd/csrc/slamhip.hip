@@ -1242,7 +1242,7 @@ k_conv_chi2(FitK g, const T* __restrict__ iunif,
             const T* __restrict__ gbt,
             const T* __restrict__ gxw, const T* __restrict__ gyw) {
   // the fixed-pitch factorised instance is only launched with 32 padded taps
-  const int kpad = (PITCH != 0 && !DIRECT) ? 32 : kpad_arg;
+  const int kpad = (PITCH != 0 && !DIRECT && sizeof(T) == 8) ? 32 : kpad_arg;
   // DIRECT (nrank == 0): the beam is not worth factorising (a rotated Gaussian
   // needs ~14 terms): direct K x K taps on the staged tile instead of row +
   // column passes
