@@ -801,7 +801,12 @@ k_profile(FitK g, const WalkerK* __restrict__ wk, const typename Real<TG>::vec2*
     // wait for the load).  Tried and not kept: walking only the stored (rank, surface)
     // pairs with four loads in flight (29.8 instead of 28.2 us/eval); entries two ranks
     // ahead in three register sets that trade places, every rank issuing the same four
-    // loads (139 VGPRs, 3 waves per SIMD: 31.0 us/eval).
+    // loads (139 VGPRs, 3 waves per SIMD: 31.0 us/eval); one register set refilled surface
+    // by surface with exactly counted loads, the guard and the lookups as two passes over
+    // the 16 sums (96 VGPRs, 5 waves per SIMD: 30.5; the same at 4 waves: 32.1); this form
+    // capped at 5 waves per SIMD (spills 52 B: 32.6).  Halving the resident workgroups
+    // (2 per CU) costs 41.0: the kernel wants occupancy, but every cheaper-register form
+    // so far pays more in extra loads and instructions than the fifth wave returns.
     unsigned fcur = 0, fnxt = __builtin_amdgcn_readfirstlane(f0v);
     unsigned fnn = f1v;
     T2 q[4], qn[4];
@@ -1429,7 +1434,7 @@ k_conv_chi2(FitK g, const T* __restrict__ iunif,
         s_rowlist[pos] = (unsigned char)tid;
       }
     }
-    if constexpr (PITCH != 0 && !DIRECT && MAXR == 2) {
+    if constexpr (PITCH != 0 && MAXR == 2) {
       // Fixed pitch: wave <-> rows wv, wv + 8, ..., a lane <-> one pair of columns.  The row
       // masks shifted by wv once; bit 8j is then row wv + 8j, every row offset an immediate.
       static_assert(TY + 31 <= 128, "two mask words cover the window's rows");
@@ -1439,7 +1444,8 @@ k_conv_chi2(FitK g, const T* __restrict__ iunif,
       constexpr int NJ = (TY + 31 + CV_NW - 1) / CV_NW;     // kpad <= 32
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
-        const bool lit = j < 8 ? ((z0 >> (8 * j)) & 1ull) : ((z1 >> (8 * (j - 8))) & 1ull);   // wave-uniform; rows past the window are never lit
+        const bool lit = DIRECT ? wv + CV_NW * j < rows    // direct taps read every row of the window
+                       : j < 8 ? ((z0 >> (8 * j)) & 1ull) : ((z1 >> (8 * (j - 8))) & 1ull);   // wave-uniform; rows past the window are never lit
         if (!lit) continue;
         if (pair) { zp[j * CV_NW * P] = 0; zp[j * CV_NW * P + 1] = 0; }
         else if (last) zp[j * CV_NW * P] = 0;
