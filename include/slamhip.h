@@ -196,7 +196,8 @@ int slamhip_beam_rank(slamhip_ctx* ctx);
 /* Selects the convolution kernel: 0 = auto (fused kernel; factorised beam or
  * direct taps, see slamhip_beam_rank), 1 = force the dense, non-fused direct
  * 2-D path, 2 = fused kernel with the factorised beam even where 0 would take
- * direct taps (cross-checks). */
+ * direct taps, 3 = fused kernel without folding the regrid into the beam taps
+ * (every walker keeps the convolved tile + bilinear regrid) (cross-checks). */
 int slamhip_set_conv_mode(slamhip_ctx* ctx, int mode);
 
 /* Measurement aid (no counterpart in the reference): between _begin and _end

@@ -2644,6 +2644,7 @@ struct slamhip_ctx {
   size_t fz_lds_direct = 0;
   bool direct_fixed = false;   // direct taps run the fixed-pitch instance
   bool sep_fixed = false;      // one-term factorised beam with kpad == 32 runs its fixed-pitch instance
+  int fold_ok = 0;             // the fit may fold the regrid into the beam (conv mode 3 switches it off)
   int persist_direct = 1;
   size_t sep_lds = 0, c2d_lds = 0, fz_lds = 0;
   hipStream_t stream = nullptr;
@@ -3534,6 +3535,7 @@ int slamhip_create(const slamhip_desc* d, slamhip_ctx** out) {
     c->fixed.wgroup = wf;
   }
   k.fold = (c->fused && c->fz_rank == 1 && !d->mom0decon) ? 1 : 0;   // one-term beam on the fused path
+  c->fold_ok = k.fold;
   HIP_TRY(c, hipStreamCreate(&c->stream));
   if (d->mom0decon && c->ob_ty) {
     // residual sum of every (channel, tile) when the model is zero there: this
@@ -3626,7 +3628,7 @@ int slamhip_beam_rank(slamhip_ctx* c) {
 }
 
 int slamhip_set_conv_mode(slamhip_ctx* c, int mode) {
-  if (!c || mode < 0 || mode > 2) return SLAMHIP_ERR_ARG;
+  if (!c || mode < 0 || mode > 3) return SLAMHIP_ERR_ARG;
   if (mode == 1 && c->f32)
     return fail(c, SLAMHIP_ERR_ARG, "conv mode 1 (dense, double) is not available at precision 1 (float)");
   if (mode == 1 && !c->k.mom0decon) {
@@ -3637,6 +3639,7 @@ int slamhip_set_conv_mode(slamhip_ctx* c, int mode) {
     if (rc) return rc;
   }
   c->conv_mode = mode;
+  c->k.fold = mode == 3 ? 0 : c->fold_ok;       // 3: conv tile + bilinear regrid for every walker
   return SLAMHIP_OK;
 }
 

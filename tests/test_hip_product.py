@@ -315,6 +315,29 @@ def test_calls_on_different_streams_are_ordered(c2):
         assert np.array_equal(cube2, cube)
 
 
+def test_folded_regrid_equals_conv_tile_plus_regrid(c2):
+    """The fused kernel folds the bilinear regrid into the beam taps for walkers whose
+    observed pixels step through consecutive model cells at one fraction (every walker of
+    this fit).  Conv mode 3 switches that off: the same walkers through the convolved
+    tile and the bilinear regrid (:475-483) must give the same sums."""
+    from slam_amd import synth
+    eng = c2.engine
+    P = synth.walkers(192, seed=23)
+    P[:, 8] = np.random.default_rng(23).uniform(-40, 40, len(P))     # xoff, yoff: any fraction,
+    P[:, 9] = np.random.default_rng(24).uniform(-40, 40, len(P))     # windows at the image edge
+    P[0, 8:10] = 0.0                                                 # fraction exactly 0
+    P[1, 8:10] = (c2.x[1] - c2.x[0]) * 3, (c2.y[1] - c2.y[0]) * -2   # whole pixels
+    folded = eng.chi2_stats(P)
+    eng.set_conv_mode(3)
+    try:
+        plain = eng.chi2_stats(P)
+    finally:
+        eng.set_conv_mode(0)
+    for key in ('gf', 'ff', 'chi2'):
+        np.testing.assert_allclose(folded[key], plain[key], rtol=1e-11, err_msg=key)
+    assert np.array_equal(eng.chi2_stats(P)['chi2'], folded['chi2'])  # and back
+
+
 @pytest.mark.timeout(1100)
 def test_c4_full_size():
     """BASELINE config 4 at full size: 1024x1024x256 cube, K = 77 beam (32-row
