@@ -807,6 +807,10 @@ k_profile(FitK g, const WalkerK* __restrict__ wk, const typename Real<TG>::vec2*
     // capped at 5 waves per SIMD (spills 52 B: 32.6).  Halving the resident workgroups
     // (2 per CU) costs 41.0: the kernel wants occupancy, but every cheaper-register form
     // so far pays more in extra loads and instructions than the fifth wave returns.
+    // Two listed items per workgroup as straight-line copies (to halve the grid's empty
+    // tail, 2.4 us/eval): the kernel's scalars then stay live across the first item, the 16
+    // scaled channel values (32 SGPRs) move to vector registers and 112 B spill inside the
+    // rank loop; the scalar budget, not the loop form, is what a second item runs into.
     unsigned fcur = 0, fnxt = __builtin_amdgcn_readfirstlane(f0v);
     unsigned fnn = f1v;
     T2 q[4], qn[4];
