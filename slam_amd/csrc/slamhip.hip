@@ -1392,27 +1392,6 @@ k_conv_chi2(FitK g, const T* __restrict__ iunif,
       }
     }
     const double* dat = g.data + (long long)k * g.ny * g.nx;
-    // folded walkers: the data under this wave's 8 cell rows, in flight until the end
-    double fdv[R];
-    unsigned fvalid = 0u;
-#pragma unroll
-    for (int r = 0; r < R; ++r) fdv[r] = 0.0;
-    if (fold_w && wv < TY / R) {
-      // this wave's cell rows wv*R .. wv*R + 7 against the window's valid range [ya, yb);
-      // the observed row of the first one, then one row pitch up or down per cell row
-      const int ya = (fyw >> 8) & 255, yb = (fyw >> 16) & 255;
-      const int rlo = max(ya - wv * R, 0), rhi = min(yb - wv * R, R);
-      if (rhi > rlo) fvalid = ((1u << rhi) - 1u) & ~((1u << rlo) - 1u);
-      const long long step = (fyw & 1) ? (long long)g.nx : -(long long)g.nx;
-      const double* rowp = dat + (long long)(head(3) + ((fyw & 1) ? wv * R : -(wv * R))) * g.nx;
-      if (pixx >= 0) {
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-          if ((fvalid >> r) & 1u) fdv[r] = rowp[pixx];      // wave-uniform test
-          rowp += step;
-        }
-      }
-    }
     const int ixa = head(1), ixb = head(2);
     const int jya = head(3), jyb = head(4);
     const int ix = ixa + lane;
@@ -1488,8 +1467,31 @@ k_conv_chi2(FitK g, const T* __restrict__ iunif,
     // -- 2. staged tiles into LDS
 #pragma unroll
     for (int u = 0; u < NSB; ++u) {
+      if (wv + CV_NW * u >= nocc) continue;                 // wave-uniform: this slot held no tile
       if (sok[u] & 1) { tile[sofs[u]] = sa[u].x; tile[sofs[u] + 1] = sa[u].y; }
       if (sok[u] & 2) { tile[sofs[u] + 16] = sb[u].x; tile[sofs[u] + 17] = sb[u].y; }
+    }
+    // folded walkers: the data under this wave's 8 cell rows, asked for only now (the wait above
+    // was for the tiles alone) and in flight until the passes are done
+    double fdv[R];
+    unsigned fvalid = 0u;
+#pragma unroll
+    for (int r = 0; r < R; ++r) fdv[r] = 0.0;
+    if (fold_w && wv < TY / R) {
+      // this wave's cell rows wv*R .. wv*R + 7 against the window's valid range [ya, yb);
+      // the observed row of the first one, then one row pitch up or down per cell row
+      const int ya = (fyw >> 8) & 255, yb = (fyw >> 16) & 255;
+      const int rlo = max(ya - wv * R, 0), rhi = min(yb - wv * R, R);
+      if (rhi > rlo) fvalid = ((1u << rhi) - 1u) & ~((1u << rlo) - 1u);
+      const long long step = (fyw & 1) ? (long long)g.nx : -(long long)g.nx;
+      const double* rowp = dat + (long long)(head(3) + ((fyw & 1) ? wv * R : -(wv * R))) * g.nx;
+      if (pixx >= 0) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          if ((fvalid >> r) & 1u) fdv[r] = rowp[pixx];      // wave-uniform test
+          rowp += step;
+        }
+      }
     }
     if (nocc > NSB * CV_NW) {
       // crowded window: the remaining occupied tiles, loaded and stored directly
