@@ -118,3 +118,42 @@ def test_real_engine_two_ranks_equal_one(tmp_path):
     mp.spawn(_gpu_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     for r in range(2):
         assert np.array_equal(np.load(tmp_path / f'g{r}.npy'), ref), r     # bitwise, on every rank
+
+
+def _nccl_worker(rank, world, port, out_dir):
+    """One rank over RCCL (backend "nccl"): the device-side collectives of the N > 1 path,
+    as far as one GPU can run them."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', 0))
+    try:
+        fit, P = _golden_fit()
+        sh = ShardedLikelihood(fit.engine.chi2_batch_torch, device='cuda')
+        assert not sh.host_wire and sh.world == 1
+        # the collectives themselves, on device tensors, as chi2() issues them for world > 1
+        t = torch.as_tensor(P, device='cuda')
+        dist.broadcast(t, src=0)
+        loc = fit.engine.chi2_batch_torch(t)
+        out = torch.empty_like(loc)
+        dist.all_gather_into_tensor(out, loc)
+        dist.barrier()
+        torch.cuda.synchronize()
+        np.save(os.path.join(out_dir, 'n0.npy'), out.cpu().numpy())
+        np.save(os.path.join(out_dir, 'n0s.npy'), sh.chi2(P, len(P)).cpu().numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(300)
+def test_rccl_collectives_on_one_rank(tmp_path):
+    """backend 'nccl' (= RCCL) with the calls the sharded path makes: broadcast of the
+    parameters, all-gather of chi2, barrier -- on a one-rank group, which is all a one-GPU
+    box can hold (two ranks on one device are refused by RCCL)."""
+    fit, P = _golden_fit()
+    ref = fit.chi2_batch(P)
+    mp.spawn(_nccl_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+    assert np.array_equal(np.load(tmp_path / 'n0.npy'), ref)
+    assert np.array_equal(np.load(tmp_path / 'n0s.npy'), ref)
