@@ -700,28 +700,18 @@ k_plan(FitK g, const WalkerK* __restrict__ wk, const float2* __restrict__ grange
 // channel, 32x8 tile) gets an occupancy byte and only occupied tiles are
 // written.  Consumers either honour the flags (k_conv_chi2) or are handed a
 // pre-zeroed buffer (dense taps).
+// One listed (walker, tile, channel block) triple, by the whole 256-thread workgroup.
 template <bool FAST, typename T, typename TG>   // T: table and accumulators, TG: geometry entries
-__global__ void __launch_bounds__(256)
-k_profile(FitK g, const WalkerK* __restrict__ wk, const typename Real<TG>::vec2* __restrict__ geom,
-          const unsigned* __restrict__ gflag, T* __restrict__ iunif, unsigned char* __restrict__ flags, int ftx, int fty,
-          unsigned char* __restrict__ winflag, int wnx, int wny, int wsx, int wsy,
-          const uint4* __restrict__ items, const int* __restrict__ nitems) {
+__device__ __forceinline__ void
+profile_item(const FitK& g, const WalkerK* __restrict__ wk, const typename Real<TG>::vec2* __restrict__ geom,
+             const unsigned* __restrict__ gflag, T* __restrict__ iunif, unsigned char* __restrict__ flags, int ftx, int fty,
+             unsigned char* __restrict__ winflag, int wnx, int wny, int wsx, int wsy,
+             const uint4* __restrict__ items, int it, T* s_prof, unsigned* s_mask) {
   using T2 = typename Real<TG>::vec2;
   // double geometry: the reference's table entry, bit for bit (lanes near a table
   // boundary redo the index in the reference's operation order); float geometry
   // cannot tell, its fast index is the index
   constexpr bool EXACT = sizeof(TG) == 8;
-  __shared__ T s_prof[PROF_LEN];
-  __shared__ unsigned s_mask[4];
-  // One workgroup per listed (walker, tile, channel block); the grid is sized for
-  // every triple, workgroups past the end of k_plan's list leave at once.
-  // XCD-aware order: blocks b and b+8 share an XCD (and its L2), and a tile's
-  // channel blocks, which all read the tile's geometry, are neighbours in the
-  // list: XCD x takes the x-th eighth of the list.
-  const int nit = *nitems;
-  const int per_xcd = (nit + 7) >> 3;
-  const int it = (int)(blockIdx.x & 7u) * per_xcd + (int)(blockIdx.x >> 3);
-  if ((int)(blockIdx.x >> 3) >= per_xcd || it >= nit) return;
   // the item carries its tile's first slot and rank count, so that the flag words and
   // the first rank's entries can be asked for at once (no table lookup in between)
   const uint4 item = items[it];                           // block-uniform: kept in SGPRs, so that
@@ -896,6 +886,53 @@ k_profile(FitK g, const WalkerK* __restrict__ wk, const typename Real<TG>::vec2*
       const int k = cix * CH + c;
       if (((m >> c) & 1u) && inb && k < g.nv) out[(long long)k * npx] = acc[c];
     }
+  }
+}
+
+// k_profile: one workgroup per listed (walker, tile, channel block).  XCD-aware order:
+// blocks b and b+8 share an XCD (and its L2), and a tile's channel blocks, which all read
+// the tile's geometry, are neighbours in the list: XCD x takes the x-th eighth of the list.
+// The host cannot know the list's length without waiting for it, and a grid sized for every
+// possible triple is mostly workgroups that leave at once (2.4 us/eval at C3): this launch
+// covers the first gridDim.x / 8 items of every eighth (a quarter of all possible triples),
+// k_profile_rest whatever a longer list leaves over.
+template <bool FAST, typename T, typename TG>
+__global__ void __launch_bounds__(256)
+k_profile(FitK g, const WalkerK* __restrict__ wk, const typename Real<TG>::vec2* __restrict__ geom,
+          const unsigned* __restrict__ gflag, T* __restrict__ iunif, unsigned char* __restrict__ flags, int ftx, int fty,
+          unsigned char* __restrict__ winflag, int wnx, int wny, int wsx, int wsy,
+          const uint4* __restrict__ items, const int* __restrict__ nitems) {
+  __shared__ T s_prof[PROF_LEN];
+  __shared__ unsigned s_mask[4];
+  const int nit = *nitems;
+  const int per_xcd = (nit + 7) >> 3;
+  const int it = (int)(blockIdx.x & 7u) * per_xcd + (int)(blockIdx.x >> 3);
+  if ((int)(blockIdx.x >> 3) >= per_xcd || it >= nit) return;
+  profile_item<FAST, T, TG>(g, wk, geom, gflag, iunif, flags, ftx, fty, winflag, wnx, wny, wsx, wsy,
+                            items, it, s_prof, s_mask);
+}
+
+// The items of each eighth beyond the first `done8`: a fixed number of workgroups walk them.
+// The loop costs registers (3 waves per SIMD instead of 4), so this is the overflow path:
+// it has work only when more than a quarter of all possible triples can hold emission.
+template <bool FAST, typename T, typename TG>
+__global__ void __launch_bounds__(256)
+k_profile_rest(FitK g, const WalkerK* __restrict__ wk, const typename Real<TG>::vec2* __restrict__ geom,
+               const unsigned* __restrict__ gflag, T* __restrict__ iunif, unsigned char* __restrict__ flags, int ftx, int fty,
+               unsigned char* __restrict__ winflag, int wnx, int wny, int wsx, int wsy,
+               const uint4* __restrict__ items, const int* __restrict__ nitems, int done8) {
+  __shared__ T s_prof[PROF_LEN];
+  __shared__ unsigned s_mask[4];
+  const int nit = *nitems;
+  const int per_xcd = (nit + 7) >> 3;
+  const int rest8 = per_xcd - done8;
+  if (rest8 <= 0) return;
+  for (int r = blockIdx.x; r < 8 * rest8; r += gridDim.x) {
+    const int it = (r & 7) * per_xcd + done8 + (r >> 3);
+    if (it < nit)                                          // block-uniform
+      profile_item<FAST, T, TG>(g, wk, geom, gflag, iunif, flags, ftx, fty, winflag, wnx, wny, wsx, wsy,
+                                items, it, s_prof, s_mask);
+    __syncthreads();                                       // table and masks free for the next item
   }
 }
 
@@ -2686,6 +2723,14 @@ struct slamhip_ctx {
   bool direct_fixed = false;   // direct taps run the fixed-pitch instance
   bool sep_fixed = false;      // one-term factorised beam with kpad == 32 runs its fixed-pitch instance
   int fold_ok = 0;             // the fit may fold the regrid into the beam (conv mode 3 switches it off)
+  // k_plan's list length of the last launch groups, copied to pinned host memory after each
+  // (never waited for): the share of all possible triples that recent groups listed sizes
+  // k_profile's one-item-per-workgroup launch for the next group; k_profile_rest covers a
+  // list that turns out longer.  -1: no value has landed yet.
+  static constexpr int HINT_SLOTS = 64;
+  int* h_nit = nullptr;
+  size_t h_ub[HINT_SLOTS] = {};
+  unsigned h_next = 0;
   int persist_direct = 1;
   size_t sep_lds = 0, c2d_lds = 0, fz_lds = 0;
   hipStream_t stream = nullptr;
@@ -3020,12 +3065,32 @@ int run_model(slamhip_ctx* c, Scratch& S, const double* d_params, int nw, hipStr
     int* nitems = S.livecount + 2;               // zeroed by k_prep with the other counters
     hipLaunchKernelGGL(k_plan, dim3((unsigned)((nw * ntile + 255) / 256)), dim3(256), 0, st, k, S.wk,
                        S.grange, nw, ntile, S.items, nitems);
-    // room for every triple (rounded up to whole groups of 8 for the XCD mapping)
-    dim3 g2((unsigned)(((size_t)nw * ntile * (k.nvpad / CH) + 7) / 8 * 8), 1, 1);
+    // One workgroup per item for as large a share of all possible triples as recent groups
+    // listed (x 1.5, + 2 %; everything while no count has come back), in eighths for the
+    // XCD mapping; a fixed grid for whatever a longer list leaves.
+    const size_t every = (size_t)nw * ntile * (k.nvpad / CH);
+    double share = -1.0;
+    for (int i = 0; i < slamhip_ctx::HINT_SLOTS; ++i) {
+      const int got = reinterpret_cast<volatile int*>(c->h_nit)[i];
+      if (got >= 0 && c->h_ub[i]) share = std::max(share, (double)got / (double)c->h_ub[i]);
+    }
+    share = share < 0.0 ? 1.0 : std::min(1.0, share * 1.5 + 0.02);
+    const int done8 = (int)std::max<size_t>(((size_t)((double)every * share) + 7) / 8, 1);
+    dim3 g2((unsigned)done8 * 8u, 1, 1), g3(2048, 1, 1);
+    {
+      const unsigned slot = c->h_next++ % slamhip_ctx::HINT_SLOTS;
+      c->h_ub[slot] = every;
+      HIP_TRY(c, hipMemcpyAsync(&c->h_nit[slot], nitems, sizeof(int), hipMemcpyDeviceToHost, st));
+    }
 #define SLAM_PROFILE(FAST_, T_, TG_, T2_)                                                         \
+    do {                                                                                          \
     hipLaunchKernelGGL((k_profile<FAST_, T_, TG_>), g2, dim3(256), 0, st, k, S.wk, (const T2_*)S.geom, \
                        S.gflag, (T_*)S.iunif, S.flags, c->ftx, c->fty, S.winflag, (int)c->fz_grid.x,  \
-                       (int)c->fz_grid.y, c->fz_sx, c->fz_sy, S.items, nitems)
+                       (int)c->fz_grid.y, c->fz_sx, c->fz_sy, S.items, nitems);                      \
+    hipLaunchKernelGGL((k_profile_rest<FAST_, T_, TG_>), g3, dim3(256), 0, st, k, S.wk, (const T2_*)S.geom, \
+                       S.gflag, (T_*)S.iunif, S.flags, c->ftx, c->fty, S.winflag, (int)c->fz_grid.x,  \
+                       (int)c->fz_grid.y, c->fz_sx, c->fz_sy, S.items, nitems, done8);               \
+    } while (0)
     if (c->g32)      { if (k.fast_idx) SLAM_PROFILE(true, float, float, float2); else SLAM_PROFILE(false, float, float, float2); }
     else if (c->f32) { if (k.fast_idx) SLAM_PROFILE(true, float, double, double2); else SLAM_PROFILE(false, float, double, double2); }
     else             { if (k.fast_idx) SLAM_PROFILE(true, double, double, double2); else SLAM_PROFILE(false, double, double, double2); }
@@ -3577,6 +3642,8 @@ int slamhip_create(const slamhip_desc* d, slamhip_ctx** out) {
   }
   k.fold = (c->fused && c->fz_rank == 1 && !d->mom0decon) ? 1 : 0;   // one-term beam on the fused path
   c->fold_ok = k.fold;
+  HIP_TRY(c, hipHostMalloc((void**)&c->h_nit, slamhip_ctx::HINT_SLOTS * sizeof(int), hipHostMallocDefault));
+  for (int i = 0; i < slamhip_ctx::HINT_SLOTS; ++i) c->h_nit[i] = -1;
   HIP_TRY(c, hipStreamCreate(&c->stream));
   if (d->mom0decon && c->ob_ty) {
     // residual sum of every (channel, tile) when the model is zero there: this
@@ -3618,6 +3685,7 @@ void slamhip_destroy(slamhip_ctx* c) {
   if (c->d_stage_p) (void)hipFree(c->d_stage_p);
   if (c->d_stage_c) (void)hipFree(c->d_stage_c);
   if (c->own.done) (void)hipEventDestroy(c->own.done);
+  if (c->h_nit) (void)hipHostFree(c->h_nit);
   for (auto& sp : c->spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;

@@ -338,6 +338,27 @@ def test_folded_regrid_equals_conv_tile_plus_regrid(c2):
     assert np.array_equal(eng.chi2_stats(P)['chi2'], folded['chi2'])  # and back
 
 
+def test_profile_list_longer_than_expected(c2):
+    """k_profile's one-item-per-workgroup launch is sized from the list lengths of recent
+    launch groups; a list that turns out longer is finished by k_profile_rest.  Sparse
+    batches first (short lists), then a dense one on the same context: bitwise the result
+    of a context that sized its launch for everything."""
+    from slam_amd import synth
+    sparse = synth.walkers(64, seed=3)
+    dense = synth.walkers(64, seed=4, workload='dense_disk')
+    ref_dense, ref_sparse = c2.chi2_batch(dense), c2.chi2_batch(sparse)
+    fit = synth.make_fit('C2')
+    try:
+        first = fit.chi2_batch(sparse)                    # no count back yet: full launch
+        again = fit.chi2_batch(sparse)                    # sized from the first call's list
+        got = fit.chi2_batch(dense)                       # list several times longer than the hint
+        assert np.array_equal(first, ref_sparse) and np.array_equal(again, ref_sparse)
+        assert np.array_equal(got, ref_dense)
+        assert np.array_equal(fit.chi2_batch(dense), ref_dense)
+    finally:
+        fit.close()
+
+
 @pytest.mark.timeout(1100)
 def test_c4_full_size():
     """BASELINE config 4 at full size: 1024x1024x256 cube, K = 77 beam (32-row
