@@ -128,7 +128,10 @@ int slamhip_chi2_batch_dev(slamhip_ctx* ctx, const double* params_dev, int nw,
  * device array of SLAMHIP_STATIC_SCRATCH_BYTES that each GPU the library runs
  * on holds until the process ends, instead of the context's allocation.  The
  * call issues no hipMalloc/hipFree, creates no events and takes as many walkers
- * per launch group as fit the array (slamhip_static_info).
+ * per launch group as fit the array (slamhip_static_info).  Like every batch
+ * entry point it enqueues, per launch group, kernels, one memset and one 4-byte
+ * copy into pinned host memory that slamhip_create allocated (a launch-sizing
+ * hint for later groups; nothing waits for it).
  * Limits: scaling 'uniform' on the fused path only (mom0decon == NULL, conv
  * modes 0 and 2); a fit that needs more than the array for ONE walker
  * (roughly 8*nv*nneed^2 + 64*2.5*npix^2 bytes: cubes up to about 256x256x64)
