@@ -22,6 +22,7 @@ from __future__ import annotations
 import numpy as np
 
 from .engine import PARAMKEYS, HipLikelihood
+from .fitspace import FitSpace
 from .utils import ReadFits, emcee_corner, rot
 
 # astropy.constants / units values the reference reads at import (:29-32):
@@ -327,90 +328,51 @@ class ChannelFit(ReadFits):
         """Free/fixed bookkeeping, log10 sampling of Mstar/Rc/Ienv, sampler
         call, result table (:539-663).  The sampler receives a vectorised
         log-probability: p[nw, ndim] -> lnp[nw]."""
-        fixed = [fixed_params.get(k) for k in self.paramkeys]
-        self.free = {k: f is None for k, f in zip(self.paramkeys, fixed)}
-        notfixed = np.array([f is None for f in fixed])
-        runfit = bool(notfixed.any())
-        base = np.array([np.nan if f is None else float(f) for f in fixed])
-        if runfit:
-            logfixed = _ILOG[~notfixed[_ILOG]]
-            with np.errstate(all='ignore'):
-                base[logfixed] = np.log10(base[logfixed])            # :580
-            labels = np.array(self.paramkeys).copy()
-            labels[_ILOG] = ['log' + labels[i] for i in _ILOG]
-            labels = labels[notfixed]
+        space = FitSpace(self.paramkeys, _ILOG, fixed_params,
+                         [Mstar_range, Rc_range, cs_range, h1_range, h2_range, pI_range,
+                          Rin_range, Ienv_range, xoff_range, yoff_range, voff_range,
+                          incl_range, pa_range])
+        self.free = space.free
+        if space.any_free:
             kw = {'nwalkers_per_ndim': 16, 'nburnin': 200, 'nsteps': 500,
-                  'labels': labels, 'rangelevel': None, 'range_corner': None,
-                  'figname': filename + '.corner.png', 'show_corner': show}
+                  'labels': space.labels(self.paramkeys), 'rangelevel': None,
+                  'range_corner': None, 'figname': filename + '.corner.png',
+                  'show_corner': show}
             kw.update(kwargs_emcee_corner)
+            kw['range_corner'] = space.corner_ranges(kw['range_corner'])     # :611-616
             bar = None
             if self.progressbar:
                 from tqdm import tqdm
-                total = kw['nwalkers_per_ndim'] * int(notfixed.sum())
-                total *= kw['nburnin'] + kw['nsteps'] + 2
-                bar = tqdm(total=total)
+                bar = tqdm(total=kw['nwalkers_per_ndim'] * space.ndim
+                           * (kw['nburnin'] + kw['nsteps'] + 2))
                 bar.set_description('Within the ranges')
 
-            def to_natural(P):
-                """sampled vectors [nw, ndim] -> natural 13-vectors (:597-599)"""
-                P = np.atleast_2d(np.asarray(P, dtype=float))
-                Q = np.tile(base, (len(P), 1))
-                Q[:, notfixed] = P
-                Q[:, _ILOG] = 10**Q[:, _ILOG]
-                return Q
-
             def lnprob(P):
-                single = np.ndim(P) == 1
-                Q = to_natural(P)
+                """sampled [nw, ndim] (or [ndim]) -> -chi2/2 per row (:597-603)"""
+                Q = space.to_natural(P)
                 if bar is not None:
                     bar.update(len(Q))
-                lnp = -0.5 * self.engine.chi2_batch(Q)               # :601-603
-                return lnp[0] if single else lnp
+                lnp = -0.5 * self.engine.chi2_batch(Q)
+                return lnp[0] if np.ndim(P) == 1 else lnp
 
-            self.lnprob = lnprob
-            self.to_natural = to_natural
-            plim = np.array([Mstar_range, Rc_range, cs_range, h1_range,
-                             h2_range, pI_range, Rin_range, Ienv_range,
-                             xoff_range, yoff_range, voff_range,
-                             incl_range, pa_range], dtype=float)
-            with np.errstate(all='ignore'):
-                plim[_ILOG] = np.log10(plim[_ILOG])
-            plim = plim[notfixed].T
-            if type(r_c := kw['range_corner']) is dict:                # :611-616
-                r_c = [r_c[k] if k in r_c else 0.8 for k in self.paramkeys]
-                for i in _ILOG:
-                    r_c[i] = r_c[i] if type(r_c[i]) is float else np.log10(r_c[i])
-                kw['range_corner'] = [a for a, k in zip(r_c, self.paramkeys)
-                                      if self.free[k]]
-            self.plim = plim
-            mcmc = emcee_corner(plim, lnprob, simpleoutput=False,
-                                vectorize=True, **kw)
+            self.lnprob, self.to_natural, self.plim = lnprob, space.to_natural, space.plim
+            mcmc = emcee_corner(space.plim, lnprob, simpleoutput=False, vectorize=True, **kw)
             if bar is not None:
                 bar.close()
-            res = [to_natural(m)[0] for m in mcmc]
-            self.popt, self.plow, self.pmid, self.phigh = res
+            self.popt, self.plow, self.pmid, self.phigh = (space.to_natural(m)[0] for m in mcmc)
         else:
-            chi2 = self.engine.chi2_batch(base[None])[0]               # :629-634
-            dof = np.prod(np.shape(self.data_valid))
-            dof = dof / self.pixperbeam - 6 - 1
+            chi2 = self.engine.chi2_batch(space.base[None])[0]         # :629-634
+            dof = np.prod(np.shape(self.data_valid)) / self.pixperbeam - 6 - 1
             self.chi2r = chi2 / dof
-            self.popt = self.plow = self.pmid = self.phigh = base
+            self.popt = self.plow = self.pmid = self.phigh = space.base
 
         self.pa_rad = self.pa_rad + np.radians(self.popt[12])           # :645-647
         self.sinpa, self.cospa = np.sin(self.pa_rad), np.cos(self.pa_rad)
-        for i, (k, d, u) in enumerate(zip(self.paramkeys, _DIGITS, _UNITS)):
-            p = [self.plow[i], self.popt[i], self.phigh[i]]
-            print(f'{k} = {p[0]:.{d:d}f}, {p[1]:.{d:d}f}, {p[2]:.{d:d}f} {u}')
-        if runfit:
-            with open(filename + '.popt.txt', 'w') as f:               # :654-659
-                f.write('#Rows:' + ','.join(self.paramkeys) + '\n')
-                f.write('#Columns:' + ','.join(['popt', 'plow', 'pmid', 'phigh']) + '\n')
-                np.savetxt(f, np.transpose([self.popt, self.plow, self.pmid,
-                                            self.phigh]))
-        self.popt = dict(zip(self.paramkeys, self.popt))
-        self.plow = dict(zip(self.paramkeys, self.plow))
-        self.pmid = dict(zip(self.paramkeys, self.pmid))
-        self.phigh = dict(zip(self.paramkeys, self.phigh))
+        space.report(self.plow, self.popt, self.phigh, _DIGITS, _UNITS)
+        if space.any_free:
+            space.write_table(filename + '.popt.txt', self.popt, self.plow, self.pmid, self.phigh)
+        for name in ('popt', 'plow', 'pmid', 'phigh'):
+            setattr(self, name, dict(zip(self.paramkeys, getattr(self, name))))
 
     # -- outputs -------------------------------------------------------------
     def _full_velocity_cube(self, m):

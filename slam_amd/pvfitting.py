@@ -12,6 +12,7 @@ from __future__ import annotations
 import numpy as np
 
 from .mockpvd import PARAMKEYS, MockPVD
+from .fitspace import FitSpace
 from .utils import ReadFits, emcee_corner
 
 _ILOG = np.array([0, 1, 2, 3, 4], dtype=int)        # _pvfitting.py:162
@@ -128,85 +129,49 @@ class PVFitting(ReadFits):
         self.makemodel = makemodel
 
         paramkeys = list(PARAMKEYS)
-        fixed = [fixed_params[k] if k in fixed_params else None for k in paramkeys]
-        free = {k: f is None for k, f in zip(paramkeys, fixed)}
-        notfixed = np.array([f is None for f in fixed])
-        base = np.array([np.nan if f is None else float(f) for f in fixed])
-        runfit = bool(notfixed.any())
-        if runfit:
-            logfixed = _ILOG[~notfixed[_ILOG]]
-            with np.errstate(all='ignore'):
-                base[logfixed] = np.log10(base[logfixed])            # :163-164
-            labels = np.array(['Mstar', 'Rc', r'$\alpha$', r'$\tau_\mathrm{max}$',
-                               r'$f_\rho$', r'$\sigma_\mathrm{model}$'])
-            labels[_ILOG] = ['log' + labels[i] for i in _ILOG]
-            labels = labels[notfixed]
+        space = FitSpace(paramkeys, _ILOG, fixed_params,
+                         [Mstar_range, Rc_range, alphainfall_range, taumax_range, frho_range,
+                          sig_mdl_range])
+        if space.any_free:
+            names = ['Mstar', 'Rc', r'$\alpha$', r'$\tau_\mathrm{max}$', r'$f_\rho$',
+                     r'$\sigma_\mathrm{model}$']
             kw = {'nwalkers_per_ndim': 4, 'nburnin': 500, 'nsteps': 500,
-                  'rangelevel': None, 'range_corner': None, 'labels': labels,
+                  'rangelevel': None, 'range_corner': None, 'labels': space.labels(names),
                   'figname': filename + '.corner.png', 'show_corner': show,
                   'plot_chain': False, 'show_chain': False}
             kw.update(kwargs_emcee_corner)
+            kw['range_corner'] = space.corner_ranges(kw['range_corner'])      # :201-206
             bar = None
             if progressbar:
                 from tqdm import tqdm
-                total = kw['nwalkers_per_ndim'] * int(notfixed.sum())
-                total *= kw['nburnin'] + kw['nsteps'] + 2
-                bar = tqdm(total=total)
+                bar = tqdm(total=kw['nwalkers_per_ndim'] * space.ndim
+                           * (kw['nburnin'] + kw['nsteps'] + 2))
                 bar.set_description('Within the ranges')
 
-            def to_natural(P):
-                """sampled [nw, ndim] -> natural 6-vectors (:185-187)"""
-                P = np.atleast_2d(np.asarray(P, dtype=float))
-                Q = np.tile(base, (len(P), 1))
-                Q[:, notfixed] = P
-                Q[:, _ILOG] = 10**Q[:, _ILOG]
-                return Q
-
             def lnprob(P):
-                single = np.ndim(P) == 1
-                Q = to_natural(P)
+                """sampled [nw, ndim] (or [ndim]) -> modified log-likelihood per row (:181-195)"""
+                Q = space.to_natural(P)
                 if bar is not None:
                     bar.update(len(Q))
-                lnp = mpvd.lnprob_batch(Q, incl, linewidth, 1., rout)   # :189-195
-                return lnp[0] if single else lnp
-            self.lnprob, self.to_natural = lnprob, to_natural
-            plim = np.array([Mstar_range, Rc_range, alphainfall_range,
-                             taumax_range, frho_range, sig_mdl_range], dtype=float)
-            with np.errstate(all='ignore'):
-                plim[_ILOG] = np.log10(plim[_ILOG])
-            plim = plim[notfixed].T
-            if type(r_c := kw['range_corner']) is dict:              # :201-206
-                r_c = [r_c[k] if k in r_c else 0.8 for k in paramkeys]
-                for i in _ILOG:
-                    r_c[i] = r_c[i] if type(r_c[i]) is float else np.log10(r_c[i])
-                kw['range_corner'] = [a for a, k in zip(r_c, paramkeys) if free[k]]
-            self.plim = plim
-            mcmc = emcee_corner(plim, lnprob, simpleoutput=False, vectorize=True, **kw)
+                lnp = mpvd.lnprob_batch(Q, incl, linewidth, 1., rout)
+                return lnp[0] if np.ndim(P) == 1 else lnp
+            self.lnprob, self.to_natural, self.plim = lnprob, space.to_natural, space.plim
+            mcmc = emcee_corner(space.plim, lnprob, simpleoutput=False, vectorize=True, **kw)
             if bar is not None:
                 bar.close()
-            popt, plow, pmid, phigh = (to_natural(m)[0] for m in mcmc)
+            popt, plow, pmid, phigh = (space.to_natural(m)[0] for m in mcmc)
         else:
-            _, st = stats_of(base)                                   # :221-236
+            _, st = stats_of(space.base)                             # :221-236
             dof = np.prod(np.shape(majobs)) + np.prod(np.shape(minobs))
-            dof = dof / np.sqrt(Rarea) - 6 - 1
-            self.chi2r = st['chi2'][0] / dof
-            popt = plow = pmid = phigh = base
-        self.popt, self.plow, self.pmid, self.phigh = popt, plow, pmid, phigh
-        ulist = ['Msun', 'au', '', '', '', 'sig_obs']
-        digits = [2, 0, 2, 2, 2, 2]
-        flist = ['f', 'f', 'f', 'e', 'e', 'f']
-        for i, (k, d, u, f) in enumerate(zip(paramkeys, digits, ulist, flist)):
-            p = [self.plow[i], self.popt[i], self.phigh[i]]
-            print(f'{k} = {p[0]:.{d:d}{f}}, {p[1]:.{d:d}{f}}, {p[2]:.{d:d}{f}} {u}')
-        if runfit:
-            with open(filename + '.popt.txt', 'w') as f:             # :253-257
-                f.write('#Rows:' + ','.join(paramkeys) + '\n')
-                f.write('#Columns:' + ','.join(['popt', 'plow', 'pmid', 'phigh']) + '\n')
-                np.savetxt(f, np.transpose([self.popt, self.plow, self.pmid, self.phigh]))
-        self.popt = dict(zip(paramkeys, self.popt))
-        self.plow = dict(zip(paramkeys, self.plow))
-        self.pmid = dict(zip(paramkeys, self.pmid))
-        self.phigh = dict(zip(paramkeys, self.phigh))
+            self.chi2r = st['chi2'][0] / (dof / np.sqrt(Rarea) - 6 - 1)
+            popt = plow = pmid = phigh = space.base
+        space.report(plow, popt, phigh, digits=[2, 0, 2, 2, 2, 2],
+                     units=['Msun', 'au', '', '', '', 'sig_obs'],
+                     formats=['f', 'f', 'f', 'e', 'e', 'f'])
+        if space.any_free:
+            space.write_table(filename + '.popt.txt', popt, plow, pmid, phigh)   # :253-257
+        self.popt, self.plow, self.pmid, self.phigh = (dict(zip(paramkeys, v))
+                                                       for v in (popt, plow, pmid, phigh))
 
     def read_fitres(self, f: str):
         """Read a <filename>.popt.txt table (_pvfitting.py:267-275)."""

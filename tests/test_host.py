@@ -237,3 +237,30 @@ def test_spherical_offsets_hand_computed():
     assert abs(ra - (4 + 39 / 60 + 53.878 / 3600) * 15) < 1e-12
     assert abs(dec - (26 + 3 / 60 + 9.43 / 3600)) < 1e-12
     assert parse_center('16h00m00s -00d30m00s')[1] == -0.5
+
+
+def test_fitspace_bookkeeping(tmp_path, capsys):
+    """Free / fixed / log-sampled rules shared by ChannelFit.fitting and fit_mockpvd."""
+    from slam_amd.fitspace import FitSpace
+    keys = ['a', 'b', 'c', 'd']
+    sp = FitSpace(keys, [0, 1], {'b': 100., 'd': 3.}, [[0.1, 10], [1, 1000], [-2, 2], [0, 5]])
+    assert sp.free == {'a': True, 'b': False, 'c': True, 'd': False} and sp.ndim == 2
+    assert np.array_equal(sp.plim, [[-1., -2.], [1., 2.]])            # log10 box of a, plain box of c
+    assert sp.base[1] == 2.0 and sp.base[3] == 3.0                    # fixed b held as log10
+    assert np.array_equal(sp.to_natural([0.5, 1.5]), [[10**0.5, 100., 1.5, 3.]])
+    assert sp.to_natural(np.zeros((7, 2))).shape == (7, 4)
+    assert list(sp.labels(keys)) == ['loga', 'c']
+    assert sp.corner_ranges(None) is None
+    r = sp.corner_ranges({'a': [1., 10.], 'c': 0.9})
+    assert np.array_equal(r[0], [0., 1.]) and r[1] == 0.9
+    assert sp.corner_ranges({'b': [1, 2]}) == [0.8, 0.8]              # only free parameters are listed
+    allfixed = FitSpace(keys, [0, 1], dict(zip(keys, [2., 100., 0., 3.])), [[1, 2]] * 4)
+    assert not allfixed.any_free and np.array_equal(allfixed.base, [2., 100., 0., 3.])   # natural
+    sp.report([1, 2, 3, 4], [5, 6, 7, 8], [9, 10, 11, 12], [2, 0, 1, 2], ['x', 'y', '', 'z'],
+              ['f', 'f', 'e', 'f'])
+    assert capsys.readouterr().out.splitlines()[2] == 'c = 3.0e+00, 7.0e+00, 1.1e+01 '
+    path = tmp_path / 't.popt.txt'
+    sp.write_table(path, [1, 2, 3, 4], [0, 0, 0, 0], [1, 1, 1, 1], [2, 2, 2, 2])
+    txt = path.read_text().splitlines()
+    assert txt[0] == '#Rows:a,b,c,d' and txt[1] == '#Columns:popt,plow,pmid,phigh'
+    assert np.array_equal(np.loadtxt(path)[:, 0], [1, 2, 3, 4])
