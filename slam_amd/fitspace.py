@@ -36,7 +36,7 @@ class FitSpace:
 
     def labels(self, names):
         """Axis labels of the sampled parameters ('log' in front of the log-sampled ones)."""
-        out = np.array(names).copy()
+        out = np.array(names, dtype=object)              # no fixed-width truncation of 'log...'
         out[self.logidx] = ['log' + out[i] for i in self.logidx]
         return out[self.free_mask]
 
