@@ -1166,9 +1166,20 @@ k_compact(FitK g, const unsigned char* __restrict__ winflag, int total,
   const bool live = e < total && winflag[e];
   const unsigned long long lanes = __ballot(live);
   const int lane = threadIdx.x & 63;
-  int slot = 0;
-  if (lane == 0 && lanes) slot = atomicAdd(count, __popcll(lanes));
-  slot = __shfl(slot, 0, 64) + __popcll(lanes & ((1ull << lane) - 1ull));
+  // ONE counter update per workgroup: returning atomics on a single address are served
+  // one after the other at memory (~12 ns each on this part: one per wave made them the
+  // kernel's whole duration), so the four waves' counts meet in LDS first
+  __shared__ int s_cnt[4], s_base;
+  if (lane == 0) s_cnt[threadIdx.x >> 6] = __popcll(lanes);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int tot = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    s_base = tot ? atomicAdd(count, tot) : 0;
+  }
+  __syncthreads();
+  int slot = s_base;
+  for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) slot += s_cnt[w];
+  slot += __popcll(lanes & ((1ull << lane) - 1ull));
   if (!live) return;
   const int n = g.nneed;
   const int z = e / (wnx * wny), tl = e - z * (wnx * wny);
