@@ -1375,9 +1375,13 @@ k_conv_chi2(FitK g, const T* __restrict__ iunif,
   int* queue = count + 1;
   if ((int)blockIdx.x >= nlive) return;                     // whole workgroup
   if (tid < DW) s_desc[0][tid] = reinterpret_cast<const unsigned*>(&list[blockIdx.x])[tid];
-  if (tid == 0) s_ticket = (int)gridDim.x + atomicAdd(queue, 1);
+  // Tickets come TICKET_B at a time: the counter is one address, its returning atomics are
+  // served one after the other at memory, and a ticket per window kept that queue two thirds busy.
+  constexpr int TICKET_B = 4;
+  if (tid == 0) s_ticket = (int)gridDim.x + atomicAdd(queue, TICKET_B);
   __syncthreads();
   int nxt = __builtin_amdgcn_readfirstlane(s_ticket);     // block-uniform, kept scalar
+  int held = TICKET_B - 1;                                // further windows of the batch after nxt
   // every wave reaches the loop exit: tickets only grow, and a workgroup stops
   // drawing once it holds one past the end of the list
   // Diagnostic build only (-DSLAMHIP_PHASE_STAMPS, `python -m slam_amd.build --stamps`):
@@ -1398,7 +1402,7 @@ k_conv_chi2(FitK g, const T* __restrict__ iunif,
     if (tid < DW && nxt < nlive)
       nextw = reinterpret_cast<const unsigned*>(&list[nxt])[tid];
     int fut = nlive;
-    if (tid == 0 && nxt < nlive) fut = (int)gridDim.x + atomicAdd(queue, 1);
+    if (held == 0 && tid == 0 && nxt < nlive) fut = (int)gridDim.x + atomicAdd(queue, TICKET_B);
     const WinDesc* cur = reinterpret_cast<const WinDesc*>(&s_desc[par][0]);   // in LDS
     // The descriptor's fields are block-uniform and live in SGPRs.  ONE LDS round
     // trip fetches them all: lane l reads dword l of the head (16 dwords: ids and
@@ -1850,7 +1854,8 @@ k_conv_chi2(FitK g, const T* __restrict__ iunif,
     }
     STAMP(7);
     it = nxt;
-    nxt = __builtin_amdgcn_readfirstlane(s_ticket);
+    if (held > 0) { nxt = nxt + 1; --held; }              // still inside the batch
+    else { nxt = __builtin_amdgcn_readfirstlane(s_ticket); held = TICKET_B - 1; }
     // the next window's first barrier orders its LDS writes after these reads
   }
 #ifdef SLAMHIP_PHASE_STAMPS
