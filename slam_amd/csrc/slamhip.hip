@@ -683,9 +683,18 @@ k_plan(FitK g, const WalkerK* __restrict__ wk, const float2* __restrict__ grange
     if (lane >= off) incl += v;
   }
   const int total = __shfl(incl, 63, 64);
-  int base = 0;
-  if (lane == 0 && total) base = atomicAdd(nitems, total);
-  base = __shfl(base, 0, 64) + incl - mine;
+  // one slot reservation per workgroup (a single counter serves its returning atomics one
+  // after the other at memory): the waves' totals meet in LDS
+  __shared__ int s_tot[4], s_base;
+  if (lane == 63) s_tot[threadIdx.x >> 6] = total;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int all = s_tot[0] + s_tot[1] + s_tot[2] + s_tot[3];
+    s_base = all ? atomicAdd(nitems, all) : 0;
+  }
+  __syncthreads();
+  int base = s_base + incl - mine;
+  for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) base += s_tot[w];
   if (mine) {
     for (int cix = 0; cix < nchunk; ++cix) {
       const double cmid = 0.5 * (g.ch_vmin[cix] + g.ch_vmax[cix]);
@@ -2535,14 +2544,22 @@ k_obs_list(FitK g, const unsigned char* __restrict__ tileflag, const double* __r
       for (int fx = fx0; fx <= fx1; ++fx) live |= fl[fy * ntx + fx] != 0;
     if (!live) partial[blk] = empty_ss[((long long)(bz % g.nv) * nty + by) * ntx + bx];
   }
+  // one slot reservation per workgroup (a single counter serves its returning atomics one
+  // after the other at memory, ~12 ns each): the waves' counts meet in LDS
   const unsigned long long m = __ballot(live);
-  if (m) {
-    const int lane = threadIdx.x & 63;
-    const int leader = __ffsll((long long)m) - 1;
-    int base = 0;
-    if (lane == leader) base = atomicAdd(&count[0], __popcll(m));
-    base = __shfl(base, leader);
-    if (live) list[base + __popcll(m & ((1ull << lane) - 1ull))] = (int)blk;
+  const int lane = threadIdx.x & 63;
+  __shared__ int s_cnt[4], s_base;
+  if (lane == 0) s_cnt[threadIdx.x >> 6] = __popcll(m);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int all = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    s_base = all ? atomicAdd(&count[0], all) : 0;
+  }
+  __syncthreads();
+  if (live) {
+    int base = s_base + __popcll(m & ((1ull << lane) - 1ull));
+    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) base += s_cnt[w];
+    list[base] = (int)blk;
   }
 }
 
@@ -2556,16 +2573,22 @@ k_conv_obs_live(FitK g, const double* __restrict__ in, double* __restrict__ part
                 int* __restrict__ count, int ntx, int nty) {
   __shared__ int s_ticket;
   const int nlive = count[0];
+  // Tickets come eight at a time: the draw is a returning atomic on one address, waited
+  // for before the window can start, and one per window left that round trip exposed.
+  constexpr int TB = 8;
   for (;;) {
-    if (threadIdx.x == 0) s_ticket = atomicAdd(&count[1], 1);
+    if (threadIdx.x == 0) s_ticket = atomicAdd(&count[1], TB);
     __syncthreads();
-    const int t = s_ticket;
-    if (t >= nlive) return;                        // every wave leaves here
-    const int blk = list[t];
-    const int bx = blk % ntx, by = (blk / ntx) % nty, bz = blk / (ntx * nty);
-    conv_obs_sep_window<TY, NIT, false>(g, in, nullptr, partial, kpad, nrank, nullptr, nullptr, gxp, gyp,
-                                        rowflag, bx, by, bz, ntx, nty);
-    __syncthreads();
+    const int t0 = s_ticket;
+    if (t0 >= nlive) return;                       // every wave leaves here
+    const int t1 = min(t0 + TB, nlive);
+    for (int t = t0; t < t1; ++t) {
+      const int blk = list[t];
+      const int bx = blk % ntx, by = (blk / ntx) % nty, bz = blk / (ntx * nty);
+      conv_obs_sep_window<TY, NIT, false>(g, in, nullptr, partial, kpad, nrank, nullptr, nullptr, gxp, gyp,
+                                          rowflag, bx, by, bz, ntx, nty);
+      __syncthreads();
+    }
   }
 }
 
