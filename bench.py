@@ -265,9 +265,18 @@ def report(args, fit, eng, world, nw_total, dt, chi2, kern, psteps, counts):
                                f'bpa={args.bpa:g} (beam rank {eng.beam_rank})',
                    'walkers_per_gpu': args.walkers, 'walkers_per_launch': eng.walkers_per_group,
                    'npix': eng.npix, 'nneed': n, 'nleaf': eng.nleaf,
-                   'chi2_checksum': float(np.sum(chi2))},
+                   'chi2_checksum': float(np.sum(chi2)),
+                   'build': build_id()},
         'roofline': roofline,
     }
+
+
+def build_id():
+    """Source hash + stamps state of the libslamhip.so this process loaded
+    (slamhip_version(); equals slam_amd.build.src_sha('slamhip') of the tree it was built from)."""
+    from slam_amd import _lib
+    sha, stamps = _lib.build_info(_lib.load().slamhip_version().decode())
+    return f'{sha} stamps={int(stamps)}'
 
 
 def synth_bytes_per_eval(e, itemsize=8):

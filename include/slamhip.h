@@ -226,7 +226,12 @@ int slamhip_group_counts(slamhip_ctx* ctx, int nw, int64_t* out);
 const char* slamhip_last_error(slamhip_ctx* ctx);
 void slamhip_destroy(slamhip_ctx* ctx);
 
-/* Library-level: number of visible GPUs (0 if none), version string. */
+/* Library-level: number of visible GPUs (0 if none), version string.
+ * The version string ends in " src=<16 hex digits> stamps=<0|1>": the hash of
+ * the sources the binary was built from (this header + slamhip.hip, see
+ * slam_amd/build.py) and whether it is the diagnostic phase-stamp build
+ * (libslamhip_stamps.so; never the product).  The Python binding refuses a
+ * library whose hash differs from the sources next to it. */
 int slamhip_device_count(void);
 const char* slamhip_version(void);
 

@@ -11,7 +11,10 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, 'libslamhip.so')
+# SLAMHIP_STAMPS=1 selects the diagnostic phase-stamp build (its own file; `python -m
+# slam_amd.build --stamps`).  Nothing else can make it the loaded library.
+STAMPS = os.environ.get('SLAMHIP_STAMPS', '') == '1'
+LIB_PATH = os.path.join(HERE, 'libslamhip_stamps.so' if STAMPS else 'libslamhip.so')
 
 NPARAM = 13
 PROF_LEN = 45
@@ -92,8 +95,32 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
+    check_build(lib.slamhip_version().decode(), 'slamhip', LIB_PATH, STAMPS)
     _lib = lib
     return lib
+
+
+def build_info(version):
+    """`src` hash and stamps state out of a version string
+    ('... src=<hash> stamps=<0|1>'; stamps is absent for libslampv)."""
+    words = dict(w.split('=', 1) for w in version.split() if '=' in w)
+    return words.get('src'), words.get('stamps', '0') == '1'
+
+
+def check_build(version, name, path, stamps=False):
+    """Refuse a binary that was not built from the sources next to it, or a
+    phase-stamp build standing in for the product (or the reverse)."""
+    from . import build as _build
+    sha, is_stamps = build_info(version)
+    want = _build.src_sha(name)
+    if want is not None and sha != want:
+        raise SlamhipError(
+            f'{path} was built from other sources (library src={sha}, tree src={want}): '
+            'rebuild with `python -m slam_amd.build`')
+    if is_stamps != stamps:
+        raise SlamhipError(
+            f'{path} reports stamps={int(is_stamps)} but SLAMHIP_STAMPS={int(stamps)}: '
+            'the phase-stamp build is diagnostic only and has its own file')
 
 
 def as_dp(a):

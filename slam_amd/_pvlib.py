@@ -8,7 +8,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-from ._lib import SlamhipError
+from ._lib import SlamhipError, check_build
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libslampv.so')
@@ -85,5 +85,6 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
+    check_build(lib.slampv_version().decode(), 'slampv', LIB_PATH)
     _lib = lib
     return lib

@@ -3337,7 +3337,20 @@ int slamhip_device_count(void) {
   return n;
 }
 
-const char* slamhip_version(void) { return "slamhip 0.2 (gfx950, fp64 / fp32)"; }
+// The build (slam_amd/build.py) passes the hash of this file + include/slamhip.h as
+// SLAM_SRC_SHA; the string also says whether this is the diagnostic phase-stamp build
+// (its own file, libslamhip_stamps.so: never the product).
+#ifndef SLAM_SRC_SHA
+#define SLAM_SRC_SHA "unknown"
+#endif
+#ifdef SLAMHIP_PHASE_STAMPS
+#define SLAMHIP_STAMPS_STATE "1"
+#else
+#define SLAMHIP_STAMPS_STATE "0"
+#endif
+const char* slamhip_version(void) {
+  return "slamhip 0.3 (gfx950, fp64 / fp32) src=" SLAM_SRC_SHA " stamps=" SLAMHIP_STAMPS_STATE;
+}
 
 const char* slamhip_last_error(slamhip_ctx* ctx) {
   return ctx ? ctx->err.c_str() : "null context";

@@ -757,7 +757,11 @@ int slampv_device_count(void) {
   return n;
 }
 
-const char* slampv_version(void) { return "slampv 0.1 (gfx950)"; }
+// SLAM_SRC_SHA: hash of this file + include/slampv.h, passed by slam_amd/build.py
+#ifndef SLAM_SRC_SHA
+#define SLAM_SRC_SHA "unknown"
+#endif
+const char* slampv_version(void) { return "slampv 0.2 (gfx950) src=" SLAM_SRC_SHA; }
 int slampv_kernel_count(void) { return PK_COUNT; }
 const char* slampv_kernel_name(int i) { return (i >= 0 && i < PK_COUNT) ? kPvNames[i] : ""; }
 
