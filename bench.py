@@ -275,8 +275,8 @@ def build_id():
     """Source hash + stamps state of the libslamhip.so this process loaded
     (slamhip_version(); equals slam_amd.build.src_sha('slamhip') of the tree it was built from)."""
     from slam_amd import _lib
-    sha, stamps = _lib.build_info(_lib.load().slamhip_version().decode())
-    return f'{sha} stamps={int(stamps)}'
+    w = _lib.build_words(_lib.load().slamhip_version().decode())
+    return f"{w.get('src')} stamps={w.get('stamps')} variant={w.get('variant')}"
 
 
 def synth_bytes_per_eval(e, itemsize=8):

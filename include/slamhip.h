@@ -227,11 +227,13 @@ const char* slamhip_last_error(slamhip_ctx* ctx);
 void slamhip_destroy(slamhip_ctx* ctx);
 
 /* Library-level: number of visible GPUs (0 if none), version string.
- * The version string ends in " src=<16 hex digits> stamps=<0|1>": the hash of
- * the sources the binary was built from (this header + slamhip.hip, see
- * slam_amd/build.py) and whether it is the diagnostic phase-stamp build
- * (libslamhip_stamps.so; never the product).  The Python binding refuses a
- * library whose hash differs from the sources next to it. */
+ * The version string ends in " src=<16 hex digits> stamps=<0|1> variant=<name>":
+ * the hash of the sources the binary was built from (this header + slamhip.hip,
+ * see slam_amd/build.py), whether it is the diagnostic phase-stamp build and
+ * which build it is ("product", or the name of a diagnostic / experiment build,
+ * which lives in its own file libslamhip_<name>.so and is never the product).
+ * The Python binding refuses a library whose hash differs from the sources next
+ * to it or whose variant is not the one asked for. */
 int slamhip_device_count(void);
 const char* slamhip_version(void);
 

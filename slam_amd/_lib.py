@@ -11,10 +11,12 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-# SLAMHIP_STAMPS=1 selects the diagnostic phase-stamp build (its own file; `python -m
-# slam_amd.build --stamps`).  Nothing else can make it the loaded library.
-STAMPS = os.environ.get('SLAMHIP_STAMPS', '') == '1'
-LIB_PATH = os.path.join(HERE, 'libslamhip_stamps.so' if STAMPS else 'libslamhip.so')
+# SLAMHIP_VARIANT=<name> selects a non-product build (its own file, libslamhip_<name>.so:
+# `stamps` = the diagnostic phase-stamp build, `python -m slam_amd.build --stamps`; others are
+# A/B builds of kernel experiments).  Nothing else can make one the loaded library.
+VARIANT = os.environ.get('SLAMHIP_VARIANT', '') or 'product'
+STAMPS = VARIANT == 'stamps'
+LIB_PATH = os.path.join(HERE, 'libslamhip.so' if VARIANT == 'product' else f'libslamhip_{VARIANT}.so')
 
 NPARAM = 13
 PROF_LEN = 45
@@ -95,32 +97,38 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    check_build(lib.slamhip_version().decode(), 'slamhip', LIB_PATH, STAMPS)
+    check_build(lib.slamhip_version().decode(), 'slamhip', LIB_PATH, VARIANT)
     _lib = lib
     return lib
 
 
+def build_words(version):
+    return dict(w.split('=', 1) for w in version.split() if '=' in w)
+
+
 def build_info(version):
     """`src` hash and stamps state out of a version string
-    ('... src=<hash> stamps=<0|1>'; stamps is absent for libslampv)."""
-    words = dict(w.split('=', 1) for w in version.split() if '=' in w)
+    ('... src=<hash> stamps=<0|1> variant=<name>'; only src for libslampv)."""
+    words = build_words(version)
     return words.get('src'), words.get('stamps', '0') == '1'
 
 
-def check_build(version, name, path, stamps=False):
+def check_build(version, name, path, variant='product'):
     """Refuse a binary that was not built from the sources next to it, or a
-    phase-stamp build standing in for the product (or the reverse)."""
+    diagnostic / experiment build standing in for the product (or the reverse)."""
     from . import build as _build
+    words = build_words(version)
     sha, is_stamps = build_info(version)
     want = _build.src_sha(name)
     if want is not None and sha != want:
         raise SlamhipError(
             f'{path} was built from other sources (library src={sha}, tree src={want}): '
             'rebuild with `python -m slam_amd.build`')
-    if is_stamps != stamps:
+    got = words.get('variant', 'product')
+    if got != variant or is_stamps != (variant == 'stamps'):
         raise SlamhipError(
-            f'{path} reports stamps={int(is_stamps)} but SLAMHIP_STAMPS={int(stamps)}: '
-            'the phase-stamp build is diagnostic only and has its own file')
+            f'{path} reports variant={got} stamps={int(is_stamps)} but SLAMHIP_VARIANT asks for '
+            f'{variant}: diagnostic and experiment builds have their own files and are never the product')
 
 
 def as_dp(a):

@@ -8,9 +8,12 @@ A library is rebuilt whenever its sidecar does not describe the current sources
 and flags (not on modification times), and `slam_amd._lib.load()` refuses a
 library whose embedded hash differs from the sources beside it.
 
-The diagnostic build with in-kernel phase stamps (`--stamps`) has its OWN output
-name, `libslamhip_stamps.so`, and is only ever loaded when the environment says
-`SLAMHIP_STAMPS=1`: it can never stand in for the product.
+Anything that is not the product is a VARIANT with its OWN output name,
+`libslamhip_<variant>.so`, which is only ever loaded when the environment names it
+(`SLAMHIP_VARIANT=<variant>`) and which says so in its version string: the
+diagnostic build with in-kernel phase stamps (`--stamps` = variant `stamps`,
+-DSLAMHIP_PHASE_STAMPS) and A/B builds of a kernel experiment
+(`--variant NAME -DFLAG ...`).  A variant can never stand in for the product.
 """
 import hashlib
 import json
@@ -27,7 +30,13 @@ TARGETS = {
     'slampv': (os.path.join(HERE, 'csrc', 'slampv.hip'), os.path.join(ROOT, 'include', 'slampv.h'),
                os.path.join(HERE, 'libslampv.so')),
 }
-STAMPS_OUT = os.path.join(HERE, 'libslamhip_stamps.so')
+
+
+def variant_out(variant):
+    return os.path.join(HERE, f'libslamhip_{variant}.so')
+
+
+STAMPS_OUT = variant_out('stamps')
 SRC, _, OUT = TARGETS['slamhip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-ffp-contract=off']
 
@@ -58,11 +67,14 @@ def read_sidecar(out):
         return None
 
 
-def _build_one(name, out, extra, force, verbose):
+def _build_one(name, out, extra, force, verbose, variant='product'):
     src, hdr, _ = TARGETS[name]
     sha = src_sha(name)
     flags = FLAGS + extra
-    want = {'src_sha': sha, 'flags': flags, 'stamps': '-DSLAMHIP_PHASE_STAMPS' in extra}
+    if variant != 'product':
+        flags = flags + [f'-DSLAM_VARIANT="{variant}"']
+    want = {'src_sha': sha, 'flags': flags, 'stamps': '-DSLAMHIP_PHASE_STAMPS' in extra,
+            'variant': variant}
     if not force and os.path.exists(out) and read_sidecar(out) == want:
         return out
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
@@ -77,15 +89,23 @@ def _build_one(name, out, extra, force, verbose):
     return out
 
 
-def build(force=False, verbose=True, stamps=False):
+def build(force=False, verbose=True, stamps=False, variant=None, defines=()):
     """Product libraries (always checked); with `stamps` ALSO the diagnostic
     libslamhip_stamps.so (k_conv_chi2 phase stamps, read by slamhip_group_counts
-    on stderr; loaded only under SLAMHIP_STAMPS=1)."""
+    on stderr); with `variant` ALSO libslamhip_<variant>.so compiled with `defines`.
+    Variants are loaded only under SLAMHIP_VARIANT=<name>."""
     outs = [_build_one(n, t[2], [], force, verbose) for n, t in TARGETS.items()]
     if stamps:
-        _build_one('slamhip', STAMPS_OUT, ['-DSLAMHIP_PHASE_STAMPS'], force, verbose)
+        _build_one('slamhip', STAMPS_OUT, ['-DSLAMHIP_PHASE_STAMPS'], force, verbose, 'stamps')
+    if variant:
+        if variant in ('product', 'stamps') or not variant.isidentifier():
+            raise ValueError(f'bad variant name {variant!r}')
+        _build_one('slamhip', variant_out(variant), list(defines), force, verbose, variant)
     return outs[0]
 
 
 if __name__ == '__main__':
-    build(force='--force' in sys.argv, stamps='--stamps' in sys.argv)
+    av = sys.argv[1:]
+    var = av[av.index('--variant') + 1] if '--variant' in av else None
+    build(force='--force' in av, stamps='--stamps' in av, variant=var,
+          defines=[a for a in av if a.startswith('-D')])

@@ -3348,8 +3348,12 @@ int slamhip_device_count(void) {
 #else
 #define SLAMHIP_STAMPS_STATE "0"
 #endif
+#ifndef SLAM_VARIANT
+#define SLAM_VARIANT "product"
+#endif
 const char* slamhip_version(void) {
-  return "slamhip 0.3 (gfx950, fp64 / fp32) src=" SLAM_SRC_SHA " stamps=" SLAMHIP_STAMPS_STATE;
+  return "slamhip 0.3 (gfx950, fp64 / fp32) src=" SLAM_SRC_SHA " stamps=" SLAMHIP_STAMPS_STATE
+         " variant=" SLAM_VARIANT;
 }
 
 const char* slamhip_last_error(slamhip_ctx* ctx) {

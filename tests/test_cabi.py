@@ -55,17 +55,19 @@ def test_loaded_library_is_the_product_build_of_these_sources():
     """the library the tests and the bench load carries the hash of
     the sources in this tree and is not the phase-stamp (diagnostic) build."""
     from slam_amd import build
-    assert not _lib.STAMPS, 'SLAMHIP_STAMPS=1 in the test environment'
+    assert _lib.VARIANT == 'product', 'SLAMHIP_VARIANT set in the test environment'
     assert os.path.basename(_lib.LIB_PATH) == 'libslamhip.so'
     lib = _lib.load()
     sha, stamps = _lib.build_info(lib.slamhip_version().decode())
     assert stamps is False
+    assert _lib.build_words(lib.slamhip_version().decode())['variant'] == 'product'
     assert sha == build.src_sha('slamhip')
     # no trace of the diagnostic code in the product binary
     blob = open(_lib.LIB_PATH, 'rb').read()
     assert b'stamp %d' not in blob
     side = build.read_sidecar(_lib.LIB_PATH)
     assert side is not None and side['src_sha'] == sha and side['stamps'] is False
+    assert side['variant'] == 'product'
 
 
 def test_stale_or_stamps_library_is_refused():
@@ -77,8 +79,16 @@ def test_stale_or_stamps_library_is_refused():
         _lib.check_build('slamhip 0.3 src=0123456789abcdef stamps=0', 'slamhip', 'x.so')
     with pytest.raises(_lib.SlamhipError, match='other sources'):
         _lib.check_build('slamhip 0.2 (gfx950, fp64 / fp32)', 'slamhip', 'x.so')   # a round-2 binary
-    with pytest.raises(_lib.SlamhipError, match='diagnostic'):
+    with pytest.raises(_lib.SlamhipError, match='never the product'):
+        _lib.check_build(f'slamhip 0.3 src={good} stamps=1 variant=stamps', 'slamhip', 'x.so')
+    with pytest.raises(_lib.SlamhipError, match='never the product'):
         _lib.check_build(f'slamhip 0.3 src={good} stamps=1', 'slamhip', 'x.so')
+    with pytest.raises(_lib.SlamhipError, match='never the product'):
+        _lib.check_build(f'slamhip 0.3 src={good} stamps=0 variant=exp1', 'slamhip', 'x.so')
+    with pytest.raises(_lib.SlamhipError, match='never the product'):
+        _lib.check_build(f'slamhip 0.3 src={good} stamps=0', 'slamhip', 'x.so', 'exp1')
+    _lib.check_build(f'slamhip 0.3 src={good} stamps=0 variant=exp1', 'slamhip', 'x.so', 'exp1')
+    _lib.check_build(f'slamhip 0.3 src={good} stamps=1 variant=stamps', 'slamhip', 'x.so', 'stamps')
 
 
 def test_build_rebuilds_on_hash_not_mtime(tmp_path, monkeypatch):
@@ -96,6 +106,8 @@ def test_build_rebuilds_on_hash_not_mtime(tmp_path, monkeypatch):
     fake.write_bytes(b'')
     (tmp_path / 'libfake.so.build.json').write_text(
         '{"src_sha": "0000000000000000", "flags": [], "stamps": false}')
+    (tmp_path / 'libfake.so.build.json').write_text(
+        '{"src_sha": "0000000000000000", "flags": [], "stamps": false, "variant": "product"}')
     build._build_one('slamhip', str(fake), [], False, False)
     assert len(calls) == 1 and any('SLAM_SRC_SHA' in a for a in calls[0])
     # the stamps build goes to its own file
