@@ -2,15 +2,18 @@
 (pvfitting/_pvfitting.py) whose model evaluations run on the MI355X.
 
 Same methods and arguments for the fitting path (put_PV, check_modelgrid,
-fit_mockpvd, read_fitres; `plot`, `show`, `title`, `log` are accepted and not acted
-on: figures and the PV FITS writer are out of this package's scope, `makemodel`
-returns the model diagrams to draw or write); the sampler receives a vectorised log-probability
-(p[nw, ndim] -> lnp[nw]) that calls libslampv.so once per ensemble half.
+fit_mockpvd, read_fitres, modeltofits).  Figures are out of this package's scope:
+`plot`, `show`, `title`, `log` are accepted, and a call that asks for a figure
+(`plot=True`, the reference's default) says once that none is drawn -- `makemodel`
+returns the model diagrams and `modeltofits` writes them.  The sampler receives a
+vectorised log-probability (p[nw, ndim] -> lnp[nw]) that calls libslampv.so once
+per ensemble half.
 """
 from __future__ import annotations
 
 import numpy as np
 
+from . import fitsio
 from .mockpvd import PARAMKEYS, MockPVD
 from .fitspace import FitSpace
 from .utils import ReadFits, emcee_corner
@@ -172,6 +175,31 @@ class PVFitting(ReadFits):
             space.write_table(filename + '.popt.txt', popt, plow, pmid, phigh)   # :253-257
         self.popt, self.plow, self.pmid, self.phigh = (dict(zip(paramkeys, v))
                                                        for v in (popt, plow, pmid, phigh))
+        if plot:
+            # the reference ends with plot_pvds (:264-265); figures are not drawn here
+            print('slam_amd.PVFitting.fit_mockpvd: no figure is drawn (plot / show / title / log '
+                  'ignored); makemodel(**popt) returns the diagrams, modeltofits() writes them.')
+
+    def modeltofits(self, filehead: str = 'best', **kwargs):
+        """Write the model and residual PV diagrams of the best-fit (or given)
+        parameters as `<filehead>.{model,residual}.{major,minor}.fits`, padded
+        with NaN rows back to the file's full velocity axis (_pvfitting.py:426-459).
+        Data only, written with this package's FITS writer.  Unlike the
+        reference, repeated calls do not keep shifting CRPIX1 (it edits the
+        stored header in place; here a copy is edited)."""
+        p = dict(self.popt if kwargs == {} else kwargs)
+        p.pop('sig_mdl', None)
+        majmod, minmod = self.makemodel(**p)
+        h = dict(self.header)
+        nx = len(self.x)
+        h['CRPIX1'] = h['CRPIX1'] - self.offpix[0]
+        blue = np.full((int(np.sum(self.vorg < np.min(self.v))), nx), np.nan)
+        red = np.full((int(np.sum(np.max(self.v) < self.vorg)), nx), np.nan)
+        out = {'model.major': majmod, 'model.minor': minmod,
+               'residual.major': self.dpvmajor - majmod,
+               'residual.minor': self.dpvminor - minmod}
+        for ext, d in out.items():
+            fitsio.write_cube(f'{filehead}.{ext}.fits', np.concatenate((blue, d, red), axis=0), h)
 
     def read_fitres(self, f: str):
         """Read a <filename>.popt.txt table (_pvfitting.py:267-275)."""

@@ -1,7 +1,8 @@
 """Host-side helpers around the likelihood: coordinate rotation, the FITS cube
 reader and the sampler driver.  Mirrors the reference `utils.py` interface
-(`rot`, `ReadFits.read_cubefits`, `emcee_corner`) for the channelfit path;
-astropy / emcee / corner are optional (absent in the build image).
+(`rot`, `ReadFits.read_cubefits`, `emcee_corner`, `dynesty_corner`) for the
+channelfit path; astropy / emcee / corner / dynesty are optional (absent in the
+build image).
 """
 from __future__ import annotations
 
@@ -311,3 +312,120 @@ def emcee_corner(bounds, log_prob_fn, args: list = [],
     if return_sampler:
         return out, sampler
     return out
+
+
+class BatchedPool:
+    """`pool=` object for dynesty: its `map` evaluates a whole queue of points
+    with ONE call of a vectorised log-likelihood where dynesty maps the
+    likelihood itself over points (the initial live points, and every batch of
+    a sampler that hands the likelihood to the pool), and falls back to an
+    ordinary serial map for anything else it is asked to map (dynesty's
+    point-evolution tasks, which call the scalar likelihood themselves).
+    `size` is the queue length dynesty fills before it calls `map`."""
+
+    def __init__(self, log_prob_vec, scalar_fn, size):
+        self.log_prob_vec, self.scalar_fn, self.size = log_prob_vec, scalar_fn, int(size)
+        self.batched_calls = self.serial_calls = 0
+
+    def map(self, fn, items):
+        items = list(items)
+        inner = getattr(fn, 'func', fn)          # dynesty wraps user functions; `.func` is the original
+        if inner is self.scalar_fn and len(items):
+            self.batched_calls += 1
+            return list(np.asarray(self.log_prob_vec(np.asarray(items, dtype=float)), dtype=float))
+        self.serial_calls += 1
+        return [fn(it) for it in items]
+
+
+def dynesty_corner(bounds,
+                   log_prob_fn, args: list = [],
+                   labels: list = None,
+                   figname: str = None,
+                   show_corner: bool = False,
+                   return_evidence: bool = False,
+                   simpleoutput: bool = True,
+                   wt_kwargs=None,
+                   vectorize: bool = False, queue_size: int | None = None,
+                   sampler_cls=None, quantile_fn=None):
+    """Dynamic nested sampling in a box prior (reference utils.py:122-174; same
+    arguments and return values; the corner figure is not drawn).
+
+    `vectorize=True`: `log_prob_fn` takes p[nw, ndim] and returns lnp[nw] (the
+    batched GPU likelihood).  dynesty itself asks for one point at a time, so the
+    sampler gets a scalar wrapper (one-row batches) plus a `BatchedPool` of
+    `queue_size` (default 8 x ndim) slots, through which the live points and any
+    likelihood batch dynesty hands to its pool are evaluated as one call.
+
+    dynesty is not importable in the build image: its results are PARITY UNPINNED
+    here (tests drive this function with a stub sampler through `sampler_cls` /
+    `quantile_fn`).  Without dynesty and without `sampler_cls` an ImportError says so.
+    """
+    ndim = len(bounds[0])
+    plim = np.array(bounds, dtype=float)
+    if sampler_cls is None:
+        try:
+            from dynesty import DynamicNestedSampler as sampler_cls
+            from dynesty import utils as dyfunc
+        except ImportError as e:
+            raise ImportError(
+                'slam_amd.utils.dynesty_corner needs the dynesty package (not installed); '
+                'use emcee_corner (built-in stretch-move sampler) or pass sampler_cls') from e
+        if quantile_fn is None:
+            quantile_fn = dyfunc.quantile
+    if quantile_fn is None:
+        quantile_fn = weighted_quantile
+
+    if vectorize:
+        def lnlike(p):
+            return float(np.asarray(log_prob_fn(np.asarray(p, dtype=float)[None, :], *args))[0])
+
+        def lnlike_vec(P):
+            return log_prob_fn(P, *args)
+    else:
+        def lnlike(p):
+            return log_prob_fn(p, *args)
+
+        def lnlike_vec(P):
+            return [log_prob_fn(p, *args) for p in P]
+
+    def ptform(u):
+        return plim[0] + (plim[1] - plim[0]) * u
+
+    kw = {}
+    pool = None
+    if vectorize:
+        pool = BatchedPool(lnlike_vec, lnlike, queue_size or 8 * ndim)
+        kw = {'pool': pool, 'queue_size': pool.size}
+    dsampler = sampler_cls(lnlike, ptform, ndim, **kw)
+    dsampler.run_nested(print_progress=False, wt_kwargs=wt_kwargs)
+    results = dsampler.results
+    if show_corner or figname is not None:
+        print('slam_amd.dynesty_corner: figures are not drawn here (figname / show_corner ignored).')
+    weights = results.importance_weights()
+    samples = np.asarray(results.samples)
+    quantiles = [quantile_fn(samps, [0.16, 0.5, 0.84], weights=weights) for samps in samples.T]
+    if return_evidence:
+        evidence = np.exp(results.logz[-1])
+        evid_err = evidence * results.logzerr[-1]
+        print(f'Evidence: {evidence:.2e} +/- {evid_err:.2e}')
+    if simpleoutput:
+        pmid = np.array(quantiles).T[1]
+        perr = np.array([(q[2] - q[0]) * 0.5 for q in quantiles])
+        return [pmid, perr]
+    popt = samples[np.argmax(results.logl), :]
+    plow, pmid, phigh = np.array(quantiles).T
+    return [popt, plow, pmid, phigh]
+
+
+def weighted_quantile(x, q, weights=None):
+    """Quantiles of weighted samples: the sorted samples against the cumulative
+    weights that precede them, normalised to end at 1, linearly interpolated --
+    the rule of `dynesty.utils.quantile`, used when dynesty's own is absent."""
+    x = np.asarray(x, dtype=float)
+    q = np.atleast_1d(q)
+    if weights is None:
+        return np.percentile(x, list(100.0 * q)).tolist()
+    order = np.argsort(x)
+    cdf = np.cumsum(np.asarray(weights, dtype=float)[order])[:-1]
+    cdf = np.append(0, cdf / cdf[-1])
+    return np.interp(q, cdf, x[order]).tolist()

@@ -190,3 +190,42 @@ def test_no_gpu_fails_loudly():
     m = model_from(f)
     with pytest.raises(SlamhipError):
         m.generate_mockpvd(0.6, 70., 0.5, 2., 5., incl=45., rout=float(f['in_rout']))
+
+
+def test_modeltofits_writes_padded_diagrams(tmp_path, capsys):
+    """PVFitting.modeltofits (_pvfitting.py:426-459): four files, NaN rows for the
+    velocity channels cropped away, CRPIX1 shifted by the cropped columns, and the
+    stored header untouched (the reference edits it in place)."""
+    nx, nv = 41, 24
+    d = np.random.default_rng(4).normal(size=(1, nv, nx))
+    h = {'CRPIX1': 21.0, 'CDELT1': 0.05, 'CRVAL1': 0.0, 'CTYPE1': 'OFFSET',
+         'CRPIX2': 1.0, 'CDELT2': 200.0, 'CRVAL2': -2000.0, 'CUNIT2': 'm/s',
+         'BMAJ': 0.3 / 3600, 'BMIN': 0.2 / 3600, 'BPA': 12.0}
+    path = str(tmp_path / 'pv.fits')
+    fitsio.write_cube(path, d, h)
+    pv = PVFitting()
+    pv.put_PV(path, path, dist=100., vsys=0.5, rmax=60., vmin=-1.9, vmax=1.5, sigma=0.1)
+    n_v, n_x = pv.dpvmajor.shape
+    assert len(pv.vorg) == nv and n_v < nv
+    model = np.arange(n_v * n_x, dtype=float).reshape(n_v, n_x)
+    seen = {}
+    pv.makemodel = lambda **p: (seen.update(p) or (model, 2 * model))
+    pv.popt = dict(Mstar=1., Rc=100., alphainfall=1., taumax=1., frho=1., sig_mdl=0.3)
+    crpix = pv.header['CRPIX1']
+    head = str(tmp_path / 'best')
+    pv.modeltofits(filehead=head)
+    pv.modeltofits(filehead=head)                      # twice: no drift of CRPIX1
+    assert 'sig_mdl' not in seen and pv.header['CRPIX1'] == crpix
+    nblue = int(np.sum(pv.vorg < pv.v.min()))
+    nred = int(np.sum(pv.vorg > pv.v.max()))
+    assert nblue + nred + n_v == nv and nblue > 0 and nred > 0
+    for ext, want in (('model.major', model), ('model.minor', 2 * model),
+                      ('residual.major', pv.dpvmajor - model),
+                      ('residual.minor', pv.dpvminor - 2 * model)):
+        got, hh = fitsio.read_primary(f'{head}.{ext}.fits')
+        assert got.shape == (nv, n_x)
+        assert np.isnan(got[:nblue]).all() and np.isnan(got[nblue + n_v:]).all()
+        assert np.array_equal(got[nblue:nblue + n_v], want)
+        assert hh['CRPIX1'] == crpix - pv.offpix[0] and hh['NAXIS1'] == n_x
+    pv.modeltofits(filehead=head, Mstar=2., Rc=50., alphainfall=1., taumax=1., frho=1.)
+    assert seen['Mstar'] == 2.
