@@ -133,17 +133,16 @@ def main():
             eng.chi2_batch_torch(mine)
         torch.cuda.synchronize()
         kern = eng.profile_end()
-        counts = None
-        if args.scaling == 'uniform':
-            # one launch group on its own, then what it touched and computed
-            wl = min(eng.walkers_per_group, args.walkers)
-            eng.chi2_batch_torch(mine[:wl].contiguous())
-            torch.cuda.synchronize()
-            try:
-                counts = eng.group_counts(wl)
-                counts['walkers'] = wl
-            except Exception as e:              # dense conv mode etc.: no accounting
-                counts = None
+        # one launch group on its own, then what it touched and computed
+        wl = min(eng.walkers_per_group, args.walkers)
+        eng.chi2_batch_torch(mine[:wl].contiguous())
+        torch.cuda.synchronize()
+        try:
+            counts = eng.group_counts(wl)
+            counts['walkers'] = wl
+        except Exception as e:                  # dense conv mode etc.: no accounting
+            print('bench: no group counts:', e, file=sys.stderr)
+            counts = None
         out = report(args, fit, eng, world, nw_total, dt, chi2, kern, psteps, counts)
         out['config']['startup_s_per_rank'] = round(startup_s, 3)   # max over ranks, outside the timed region
         if world == 1 and args.cpu_evals > 0:
@@ -155,15 +154,19 @@ def main():
         dist.destroy_process_group()
 
 
-def kernel_model(eng, fit, counts, itemsize=8, geomsize=8):
+def kernel_model(eng, fit, counts, itemsize=8, geomsize=8, scaling='uniform'):
     """Per launch group: the bytes each hot kernel MUST move in this design and the
-    FP64 lane-operations it executes, from slamhip_group_counts.
-    Tiles are 32x8 pixels; a geometry entry is {vlos, weight} = 2 values."""
+    USEFUL floating-point operations it needs, from slamhip_group_counts and
+    slamhip_window_shape.  Useful = real taps only: K per axis, K+1 when
+    the regrid is folded into the beam; the kernels run the tap count padded to a multiple of 8
+    (`kpad`), and that padding is not counted.  Tiles are 32x8 pixels; a geometry entry is
+    {vlos, weight} = 2 values."""
     B = itemsize
     W = counts['walkers']
     K = fit.gaussbeam.shape[0]
-    kpad = (K + 7) // 8 * 8
-    ty = 64 if (63 + kpad)**2 * 8 + 16 * kpad <= 156 * 1024 else 32   # conv window rows (as slamhip_create picks)
+    ws = eng.window_shape()
+    kpad, ty, tx = ws['kpad'], ws['rows'], ws['cols']
+    rank = eng.beam_rank
     nslot = eng.nleaf                          # >= samples; padding ignored
     tile = 32 * 8 * B
     geom = counts['geom_groups'] * 64 * 2 * geomsize
@@ -172,17 +175,32 @@ def kernel_model(eng, fit, counts, itemsize=8, geomsize=8):
         'k_surface': -(-W // 8) * nslot * (4 + 2 * 8) + geom + W * (nslot // 64) * 4,
         # reads the stored entries (once: the channel blocks of a tile share an L2), writes lit tiles + flags
         'k_profile': geom + counts['lit_planes'] * (tile + 1),
-        # reads every lit tile once, the data under every live window, its descriptor
-        'k_conv': counts['lit_planes'] * tile + counts['live_windows'] * (63 * (ty - 1) * 8 + 240),
     }
     fl = {
         # table lookups: 16 channels x (index add + multiply-add) per hit
         'k_profile': counts['profile_hits'] * 16 * 3,
-        # row pass over rows with emission, column pass over executed 8x8 tap blocks, 64 lanes each
-        'k_conv': 2 * 64 * (counts['window_rows'] * kpad + counts['col_blocks'] * 64),
     }
-    if eng.beam_rank == 0:
-        fl.pop('k_conv')        # direct K x K taps skip tap blocks over empty rows: not counted here
+    if scaling == 'uniform':
+        # reads every lit tile once, the data under every live window, its descriptor
+        by['k_conv'] = counts['lit_planes'] * tile + counts['live_windows'] * ((tx - 1) * (ty - 1) * 8 + 240)
+        if rank >= 1:
+            taps = K + 1 if (ws['fold'] and rank == 1) else K
+            # row pass: every row with emission, tx outputs x taps; column pass: executed blocks of
+            # 8 output rows x 8 tap rows x 64 lanes, of which taps / kpad are real taps
+            fl['k_conv'] = 2 * rank * (counts['window_rows'] * tx * taps
+                                       + counts['col_blocks'] * 64 * 8 * 8 * taps / kpad)
+        else:
+            # direct taps: executed (output-row block, 8-tap-row block) pairs, once per tap column,
+            # rb x 8 multiply-adds per lane each; K of kpad tap rows are real
+            rb = 16 if ty == 64 else 8
+            fl['k_conv'] = 2 * 64 * rb * 8 * K * counts['col_blocks'] * K / kpad
+    else:
+        # 'mom0*': beam on the observed grid, dense inside every listed window (row pass over the
+        # window + halo rows, column pass over its rows), one pass pair per beam term
+        terms = max(rank, 1)
+        fl['k_conv'] = 2 * terms * counts['live_windows'] * tx * K * ((ty + K - 1) + ty)
+        # the regridded cube under the window + halo (marked segments; upper bound), data under it
+        by['k_conv'] = counts['live_windows'] * ((ty + K - 1) * (tx + K - 1) + ty * tx) * 8
     return by, fl
 
 
@@ -201,10 +219,10 @@ def report(args, fit, eng, world, nw_total, dt, chi2, kern, psteps, counts):
         dense['k_conv'] += dense.pop('k_regrid')       # fused: conv + regrid + chi2 in one kernel
     evals_prof = args.walkers * psteps
     total_ms = sum(v[0] for v in kern.values())
-    isz = 8 if args.dtype == 'f64' else 4
-    model_b, model_f = (kernel_model(eng, fit, counts, isz, 4 if args.dtype == 'f32g' else 8)
+    model_b, model_f = (kernel_model(eng, fit, counts, B, 4 if args.dtype == 'f32g' else 8, args.scaling)
                         if counts else ({}, {}))
     peak_flops = FP64_PEAK if args.dtype == 'f64' else FP32_PEAK
+    valu = 'fp64_valu' if args.dtype == 'f64' else 'fp32_valu'
     groups = -(-args.walkers // eng.walkers_per_group)          # launch groups per step
     per_kernel = {}
     for name, (ms, cnt) in kern.items():
@@ -222,12 +240,13 @@ def report(args, fit, eng, world, nw_total, dt, chi2, kern, psteps, counts):
                 d['hbm_GBps'] = model_b[name] / sec / 1e9
                 d['hbm_frac'] = model_b[name] / sec / HBM_PEAK
             if name in model_f:
-                d['fp64_ops_per_launch'] = model_f[name]      # counted operations (float ones at f32)
-                d['fp64_TFLOPs'] = model_f[name] / sec / 1e12
-                d['fp64_frac'] = model_f[name] / sec / peak_flops
+                d['flops_per_launch'] = model_f[name]         # useful operations (float ones at f32)
+                d['TFLOPs'] = model_f[name] / sec / 1e12
+                d['valu_frac'] = model_f[name] / sec / peak_flops
         per_kernel[name] = d
     dom = max((k for k in per_kernel if k in dense), key=lambda k: kern[k][0])
     dk = per_kernel[dom]
+    sec = dk['ms_per_launch'] * 1e-3
     traffic, traffic_note = measured_traffic(dom, args, eng)
     roofline = {'kernel': dom, 'ms_per_launch': dk['ms_per_launch'], 'launches': dk['launches'],
                 'traffic': traffic, 'traffic_source': traffic_note,
@@ -237,16 +256,26 @@ def report(args, fit, eng, world, nw_total, dt, chi2, kern, psteps, counts):
                              'algorithmic_x_peak': bytes_eval * nw_total * args.steps / world / dt / HBM_PEAK,
                              'kernel_ms_per_eval': total_ms / evals_prof}}
     if traffic is not None:
-        roofline['traffic_frac'] = traffic / (dk['ms_per_launch'] * 1e-3) / HBM_PEAK
-    if 'fp64_frac' in dk:
-        # the binding resource of this design is the FP64 vector pipe (arithmetic intensity
-        # of the compulsory traffic is above the machine balance): fraction against THAT
-        roofline.update({'bound': 'fp64_valu' if args.dtype == 'f64' else 'fp32_valu',
-                         'achieved': dk['fp64_TFLOPs'], 'peak': peak_flops / 1e12,
-                         'unit': 'TFLOP/s', 'frac': dk['fp64_frac'],
-                         'hbm': {'achieved': dk['hbm_GBps'], 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
-                                 'frac': dk['hbm_frac'], 'bytes_per_launch': dk['bytes_per_launch']},
-                         'counts': counts})
+        roofline['traffic_frac'] = traffic / sec / HBM_PEAK
+    if 'flops_per_launch' in dk and 'bytes_per_launch' in dk:
+        # Both roofs of the dominant kernel; the BOUND is the one its arithmetic intensity
+        # selects: useful operations per byte it moves (the measured HBM-side traffic of the
+        # committed PMC passes when they describe this build and workload, else the bytes the
+        # design must move) against the machine balance peak_flops / HBM_PEAK.
+        F, Bc = dk['flops_per_launch'], dk['bytes_per_launch']
+        Bm = traffic if traffic is not None else Bc
+        ai, balance = F / Bm, peak_flops / HBM_PEAK
+        roofs = {valu: {'achieved': F / sec / 1e12, 'peak': peak_flops / 1e12, 'unit': 'TFLOP/s',
+                        'frac': F / sec / peak_flops, 'useful_flops_per_launch': F},
+                 'hbm': {'achieved': Bm / sec / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
+                         'frac': Bm / sec / HBM_PEAK, 'bytes_per_launch': Bm,
+                         'bytes': 'measured' if traffic is not None else 'compulsory (model)',
+                         'compulsory_bytes_per_launch': Bc, 'compulsory_frac': Bc / sec / HBM_PEAK}}
+        bound = 'hbm' if ai < balance else valu
+        roofline.update({'bound': bound, 'achieved': roofs[bound]['achieved'], 'peak': roofs[bound]['peak'],
+                         'unit': roofs[bound]['unit'], 'frac': roofs[bound]['frac'],
+                         'arithmetic_intensity_flop_per_byte': ai, 'machine_balance_flop_per_byte': balance,
+                         'roofs': roofs, 'counts': counts})
     else:
         roofline.update({'bound': 'hbm', 'achieved': None, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
                          'frac': None})
@@ -453,31 +482,42 @@ def cpu_baseline_multi(args):
             'seconds': max(inner), 'wall_seconds_with_setup': wall}
 
 
+TRAFFIC_PROFILE = 'r3_traffic.json'
+
+
 def measured_traffic(kernel, args, eng):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes
+    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes
     (FETCH_SIZE and WRITE_SIZE in separate runs, FETCH_SIZE doubled as
     MI355X_MICROARCH.md's HBM section prescribes for gfx950; calibration on
-    kernels of known size is in DESIGN.md).  bench.py itself cannot read the
-    counters, so this is the figure of the profiled run of the same command;
-    null if no matching profile is committed."""
-    path = os.path.join(ROOT, 'profiles', 'r2_traffic.json')
+    kernels of known size is in DESIGN.md; Infinity-Cache hits are included in
+    FETCH_SIZE, so this is an upper bound on HBM bytes).  bench.py itself cannot
+    read the counters, so this is the figure of the profiled run of the same
+    command BY THE SAME BUILD: the profile carries the source hash of the library
+    it was collected with (`_meta.src_sha`), and a profile of other sources, another
+    workload or another launch-group size is refused (null + the reason)."""
+    path = os.path.join(ROOT, 'profiles', TRAFFIC_PROFILE)
     try:
         t = json.load(open(path))
     except Exception:
-        return None, None
+        return None, f'no profiles/{TRAFFIC_PROFILE}'
     meta = t.get('_meta', {})
-    if args.scaling != 'uniform' or args.workload != 'sparse' or args.dtype != 'f64':
-        return None, None
-    if (meta.get('config') != args.config or meta.get('walkers_per_launch') != eng.walkers_per_group
-            or meta.get('bpa') != args.bpa or args.walkers % eng.walkers_per_group):     # full launch groups only
-        return None, None
+    from slam_amd import build as _build
+    if meta.get('src_sha') != _build.src_sha('slamhip'):
+        return None, (f"stale profile: profiles/{TRAFFIC_PROFILE} was collected with src "
+                      f"{meta.get('src_sha')}, this build is {_build.src_sha('slamhip')}")
+    want = {'config': args.config, 'walkers_per_launch': eng.walkers_per_group, 'bpa': args.bpa,
+            'scaling': args.scaling, 'workload': args.workload, 'dtype': args.dtype}
+    got = {k: meta.get(k) for k in want}
+    if got != want or args.walkers % eng.walkers_per_group:     # full launch groups only
+        return None, f'profile is for {got}'
     names = {'k_conv': 'k_conv_chi2', 'k_profile': 'k_profile', 'k_surface': 'k_surface',
              'k_regrid': 'k_regrid'}
     for k, v in t.items():
         if k.startswith(names.get(kernel, kernel)):
             return (2.0 * v['fetch_bytes_per_launch_max'] + v['write_bytes_per_launch_max'],
-                    'profiles/r2_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 / WRITE_SIZE, separate passes, max over launches)')
-    return None, None
+                    f'profiles/{TRAFFIC_PROFILE} (rocprofv3 --pmc FETCH_SIZE x2 / WRITE_SIZE, separate passes, '
+                    'max over launches; same src_sha)')
+    return None, 'kernel not in profile'
 
 
 def cpu_baseline(fit, P, chi2_gpu, nevals):

@@ -190,6 +190,16 @@ int slamhip_prof(slamhip_ctx* ctx, double cs, double* prof_out,
 int slamhip_info(slamhip_ctx* ctx, int64_t* nleaf, int32_t* walkers_per_group,
                  int32_t* separable_beam);
 
+/* Introspection for the accounting in bench.py (no counterpart in the
+ * reference): output rows and columns of one beam-convolution window of the
+ * batch path (the fused kernel's window on the model grid; with a 'mom0*'
+ * scaling the beam window on the observed grid; rows = 0 if the path has no
+ * windowed kernel), the beam's tap count padded to the kernels' unroll, and 1 if
+ * walkers whose regrid is a constant-fraction shift get it folded into the beam
+ * taps (K+1 taps per axis). */
+int slamhip_window_shape(slamhip_ctx* ctx, int32_t* rows, int32_t* cols, int32_t* kpad,
+                         int32_t* fold);
+
 /* Number of outer-product terms the fused convolution uses for the beam: 1 for
  * an axis-aligned Gaussian; 0 = direct K x K taps, which is what a rotated
  * Gaussian gets (its factorisation, singular triplets down to a 1e-13 tail,
@@ -213,14 +223,18 @@ int slamhip_profile_begin(slamhip_ctx* ctx);
 int slamhip_profile_end(slamhip_ctx* ctx, double* total_ms, int64_t* launches);
 
 /* Measurement aid (no counterpart in the reference): what the context's LAST
- * launch group of `nw` walkers (fused scaling='uniform' path) touched and
- * computed, counted from the scratch it left: out[0] live conv windows,
- * [1] occupied 32x8 Iunif tiles under them (halo included), [2] window rows with
- * emission, [3] column-pass tap blocks executed, [4] lit (tile, channel) planes
+ * launch group of `nw` walkers touched and computed, counted from the scratch
+ * it left: out[0] live conv windows, [1] occupied 32x8 Iunif tiles under them
+ * (halo included), [2] window rows with emission, [3] tap blocks executed (the
+ * column pass's 8-row x 8-tap blocks of the factorised beam; for direct taps
+ * the (16- or 8-row output block, 8-tap-row block) pairs that are not skipped,
+ * each run once per tap column), [4] lit (tile, channel) planes
  * of Iunif, [5] stored geometry groups (64 samples x surface), [6] k_profile
  * hits (lane, sample, surface, 16-channel block), [7] the same per 64-sample
- * wave (at least one lane hit).  bench.py prices the
- * kernels' compulsory bytes and useful FP64 operations from these. */
+ * wave (at least one lane hit).  With a 'mom0*' scaling out[0] is the number of
+ * beam windows on the observed grid that held emission and [1]-[3] are 0.
+ * bench.py prices the kernels' compulsory bytes and useful FP64 operations
+ * from these.  Not available in the dense conv mode (1). */
 int slamhip_group_counts(slamhip_ctx* ctx, int nw, int64_t* out);
 
 const char* slamhip_last_error(slamhip_ctx* ctx);

@@ -63,6 +63,7 @@ SYMBOLS = {
     'slamhip_prof': (C.c_int, [C.c_void_p, C.c_double, _dp, _dp]),
     'slamhip_info': (C.c_int, [C.c_void_p, C.POINTER(C.c_int64),
                                C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    'slamhip_window_shape': (C.c_int, [C.c_void_p] + [C.POINTER(C.c_int32)] * 4),
     'slamhip_beam_rank': (C.c_int, [C.c_void_p]),
     'slamhip_set_conv_mode': (C.c_int, [C.c_void_p, C.c_int]),
     'slamhip_kernel_count': (C.c_int, []),

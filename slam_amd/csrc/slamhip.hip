@@ -1301,6 +1301,12 @@ k_compact(FitK g, const unsigned char* __restrict__ winflag, int total,
 // [y0, y0+TY-1) with x0 = bx*(TX-1), y0 = by*(TY-1).
 constexpr int CV_NT = 512;                   // threads per workgroup
 constexpr int CV_NW = CV_NT / 64;            // waves
+#ifndef CV_MINW_F32
+// waves per SIMD the float instances are compiled for: their tile is half the size, three
+// workgroups fit a CU's LDS, and 80 VGPRs (44 B of scratch in the hot instance) buy that
+// third workgroup: k_conv_chi2 22.9 instead of 26.2 us/eval at C3
+#define CV_MINW_F32 6
+#endif
 
 // Workgroup barrier for LDS traffic only: waits for this wave's LDS operations, not
 // for its global loads (__syncthreads() also drains vmcnt, which would expose the
@@ -1333,7 +1339,7 @@ __device__ __forceinline__ void row_taps(const T* row, const T* __restrict__ wx,
 // kpad); MULTI: the factorised beam may have several terms (false: exactly one, the column
 // pass's sums are then born after the row pass and cost it no registers)
 template <int TY, int MAXR, bool DIRECT, int PITCH = 0, typename T = double, bool MULTI = true>
-__global__ void __launch_bounds__(CV_NT, 4)
+__global__ void __launch_bounds__(CV_NT, (sizeof(T) == 4 ? CV_MINW_F32 : 4))
 k_conv_chi2(FitK g, const T* __restrict__ iunif,
             const int* __restrict__ cellx, const double* __restrict__ fracx,
             const int* __restrict__ celly, const double* __restrict__ fracy,
@@ -2067,7 +2073,10 @@ __device__ inline void count_add(unsigned long long* dst, unsigned long long v) 
 
 __global__ void __launch_bounds__(256)
 k_count_windows(const WinDesc* __restrict__ list, const int* __restrict__ count, int ty, int kpad,
-                unsigned long long* __restrict__ cnt) {
+                int rb, unsigned long long* __restrict__ cnt) {
+  // rb: output rows per tap block -- CONV_R for the column pass of the factorised form; the
+  // direct-tap form works on blocks of 2*CONV_R (64-row windows) or CONV_R output rows and
+  // skips a block of CONV_R tap rows when the rb + CONV_R - 1 window rows under it are empty
   const int nlive = count[0];
   unsigned long long nocc = 0, rows = 0, blocks = 0, live = 0;
   for (int e = blockIdx.x * 256 + threadIdx.x; e < nlive; e += gridDim.x * 256) {
@@ -2075,12 +2084,12 @@ k_count_windows(const WinDesc* __restrict__ list, const int* __restrict__ count,
     live += 1;
     nocc += d.nocc;
     rows += __popcll(d.rowmask[0]) + __popcll(d.rowmask[1]) + __popcll(d.rowmask[2]) + __popcll(d.rowmask[3]);
-    for (int wv = 0; wv < ty / CONV_R; ++wv)
-      for (int u0 = 0; u0 < kpad; u0 += CONV_R) {             // as the column pass of k_conv_chi2
-        const int ra = wv * CONV_R + u0, w0 = ra >> 6, sh = ra & 63;
+    for (int wv = 0; wv < ty / rb; ++wv)
+      for (int u0 = 0; u0 < kpad; u0 += CONV_R) {             // as the column pass / direct taps of k_conv_chi2
+        const int ra = wv * rb + u0, w0 = ra >> 6, sh = ra & 63;
         const unsigned long long lo = d.rowmask[w0], hi = w0 < 3 ? d.rowmask[w0 + 1] : 0ull;
         const unsigned long long bits = (lo >> sh) | (sh ? (hi << (64 - sh)) : 0ull);
-        if (bits & ((1ull << (2 * CONV_R - 1)) - 1ull)) blocks += 1;
+        if (bits & ((1ull << (rb + CONV_R - 1)) - 1ull)) blocks += 1;
       }
   }
   count_add(&cnt[0], live);
@@ -3755,6 +3764,16 @@ int slamhip_info(slamhip_ctx* c, int64_t* nleaf, int32_t* wgroup, int32_t* sep) 
   return SLAMHIP_OK;
 }
 
+int slamhip_window_shape(slamhip_ctx* c, int32_t* rows, int32_t* cols, int32_t* kpad, int32_t* fold) {
+  if (!c) return SLAMHIP_ERR_ARG;
+  const bool mom0 = c->k.mom0decon != nullptr;
+  if (rows) *rows = mom0 ? c->ob_ty : (c->fused ? c->fz_sy + 1 : 0);
+  if (cols) *cols = mom0 ? C2_TX : CONV_TX;
+  if (kpad) *kpad = c->kpad;
+  if (fold) *fold = c->k.fold;
+  return SLAMHIP_OK;
+}
+
 int slamhip_kernel_count(void) { return KID_COUNT; }
 
 const char* slamhip_kernel_name(int i) {
@@ -4103,8 +4122,9 @@ int slamhip_prof(slamhip_ctx* c, double cs, double* prof_out, double* prof_d_out
 int slamhip_group_counts(slamhip_ctx* c, int nw, int64_t* out) {
   if (!c || c->wgroup < 1) return SLAMHIP_ERR_STATE;
   if (!out || nw < 1 || nw > c->own.wgroup) return fail(c, SLAMHIP_ERR_ARG, "group_counts: bad arguments");
-  if (c->k.mom0decon || !c->fused || c->conv_mode == 1)
-    return fail(c, SLAMHIP_ERR_ARG, "group_counts: fused scaling='uniform' path only");
+  const bool mom0 = c->k.mom0decon != nullptr;
+  if ((!mom0 && !c->fused) || c->conv_mode == 1 || (mom0 && !(c->ob_ty && c->d_oblist)))
+    return fail(c, SLAMHIP_ERR_ARG, "group_counts: fused / listed-window paths only (not the dense conv mode)");
   HIP_TRY(c, hipSetDevice(c->device));
   Scratch& S = c->own;
   int rc = scratch_acquire(c, S, c->stream);
@@ -4113,8 +4133,13 @@ int slamhip_group_counts(slamhip_ctx* c, int nw, int64_t* out) {
   // the counters live in the (re-initialised every group) tail of the ticket words
   unsigned long long* cnt = reinterpret_cast<unsigned long long*>(S.livecount + 16);
   HIP_TRY(c, hipMemsetAsync(cnt, 0, 8 * sizeof(unsigned long long), c->stream));
-  hipLaunchKernelGGL(k_count_windows, dim3(512), dim3(256), 0, c->stream, S.livelist, S.livecount,
-                     c->fz_sy + 1, c->kpad, cnt);
+  if (!mom0) {
+    const int ty = c->fz_sy + 1;
+    const int fz_rank = (c->conv_mode == 2 && c->nrank >= 1) ? c->nrank : c->fz_rank;
+    const int rb = fz_rank ? CONV_R : (ty == 64 ? 2 * CONV_R : CONV_R);
+    hipLaunchKernelGGL(k_count_windows, dim3(512), dim3(256), 0, c->stream, S.livelist, S.livecount,
+                       ty, c->kpad, rb, cnt);
+  }
   hipLaunchKernelGGL(k_count_flags, dim3(1024), dim3(256), 0, c->stream, S.flags,
                      (long long)nw * k.nv * c->ftx * c->fty, S.gflag, (long long)nw * (k.nslot >> 6), cnt);
   if (c->g32)
@@ -4129,6 +4154,11 @@ int slamhip_group_counts(slamhip_ctx* c, int nw, int64_t* out) {
   rc = single_finish(c, e, "group_counts");
   if (rc) return rc;
   for (int i = 0; i < 8; ++i) out[i] = (int64_t)h[i];
+  if (mom0) {     // 'mom0*' scalings: the beam windows with emission that k_obs_list listed for the last group
+    int live = 0;
+    HIP_TRY(c, hipMemcpy(&live, c->d_obcount, sizeof live, hipMemcpyDeviceToHost));
+    out[0] = live;
+  }
 #ifdef SLAMHIP_PHASE_STAMPS
   {
     unsigned long long h2[8];

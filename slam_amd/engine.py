@@ -91,6 +91,13 @@ class HipLikelihood:
         self.nleaf, self.walkers_per_group = nleaf.value, wg.value
         self.separable_beam = bool(sep.value)
         self.beam_rank = int(self._lib.slamhip_beam_rank(self._ctx))
+        self.kbeam = K
+
+    def window_shape(self):
+        """dict(rows, cols, kpad, fold) of the batch path's beam window (slamhip_window_shape)."""
+        v = [C.c_int32() for _ in range(4)]
+        self._check(self._lib.slamhip_window_shape(self._ctx, *[C.byref(x) for x in v]), 'window_shape')
+        return dict(zip(('rows', 'cols', 'kpad', 'fold'), (x.value for x in v)))
 
     # -- plumbing ----------------------------------------------------------
     def _errmsg(self):

@@ -8,14 +8,14 @@ def show(d):
     r = d['roofline']
     print(f"{d['config']['workload']}")
     print(f"  evals/s {d['value']:.1f}  ms/step {d['ms_per_step']:.2f}  bound {r.get('bound')}"
-          f"  frac {r.get('frac')}  hbm {r.get('hbm', {}).get('frac')}  traffic_frac {r.get('traffic_frac')}"
+          f"  frac {r.get('frac')}  AI {r.get('arithmetic_intensity_flop_per_byte')}  traffic_frac {r.get('traffic_frac')}"
           f"  dense-bytes x peak {r.get('algorithmic_x_peak')}")
     for k, v in r['per_kernel'].items():
         extra = ''
         if 'hbm_frac' in v:
             extra += f"  hbm {v['hbm_frac']:.3f}"
-        if 'fp64_frac' in v:
-            extra += f"  fp64 {v['fp64_frac']:.3f}"
+        if 'valu_frac' in v:
+            extra += f"  valu {v['valu_frac']:.3f}"
         print(f"    {k:12s} {v['ms_per_launch']:9.4f} ms/launch x{v['launches']:<4d} "
               f"{v['ms_per_eval'] * 1e3:8.2f} us/eval  share {v['share']:.3f}{extra}")
     if 'cpu_baseline' in d:

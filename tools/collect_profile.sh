@@ -11,4 +11,5 @@ timeout -k 10 600 python bench.py "$@" > $out/bench.json 2> $out/bench.err || ex
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python bench.py --cpu-evals 0 "$@" > $out/trace.log 2>&1 || exit 2
 timeout -s KILL 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/fetch -- python bench.py --cpu-evals 0 --steps 1 --warmup 0 "$@" > $out/fetch.log 2>&1 || exit 3
 timeout -s KILL 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/write -- python bench.py --cpu-evals 0 --steps 1 --warmup 0 "$@" > $out/write.log 2>&1 || exit 4
+timeout -s KILL 300 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $out/l2 -- python bench.py --cpu-evals 0 --steps 1 --warmup 0 "$@" > $out/l2.log 2>&1 || exit 5
 echo done

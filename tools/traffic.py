@@ -31,6 +31,15 @@ def counter_rows(d, counter):
     return per
 
 
+def counter_rows_raw(d, counter):
+    f = max(glob.glob(os.path.join(d, '*', '*_counter_collection.csv')), key=os.path.getmtime)
+    per = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if r['Counter_Name'] == counter:
+            per[short(r['Kernel_Name'])].append(float(r['Counter_Value']))
+    return per
+
+
 def main():
     tag = sys.argv[1]
     src = f'gpurun_out/prof_{tag}'
@@ -50,10 +59,24 @@ def main():
                   'write_bytes_per_launch': sum(w) / max(len(w), 1),
                   'write_bytes_per_launch_max': max(w) if w else 0.0}
     b = json.loads(bench)
-    out['_meta'] = {'config': 'C3' if '512x512x128' in b['metric'] else b['metric'].split()[-1],
+    w = b['config']['workload']          # 'SYN-v1 C3 (sparse, f64): ... bpa=0 (beam rank 1)'
+    m = re.match(r'SYN-v1 (\w+) \((\w+), (\w+)\).* bpa=([-\d.e+]+) ', w)
+    scaling = re.search(r'scaling=(\w+)', b['metric'])
+    out['_meta'] = {'config': m.group(1), 'workload': m.group(2), 'dtype': m.group(3),
+                    'bpa': float(m.group(4)), 'scaling': scaling.group(1) if scaling else 'uniform',
                     'walkers_per_launch': b['config']['walkers_per_launch'],
-                    'bpa': 0.0 if 'bpa=0 ' in b['config']['workload'] else None,
-                    'fetch_correction': 'FETCH_SIZE x2 (gfx950 counts 64 B per 128-B request)'}
+                    # the build the counters were collected with: bench.py refuses the profile
+                    # for any other (slam_amd/build.py src_sha)
+                    'src_sha': b['config']['build'].split()[0],
+                    'fetch_correction': 'FETCH_SIZE x2 (gfx950 counts 64 B per 128-B request); '
+                                        'Infinity-Cache hits are included (upper bound on HBM bytes)'}
+    hm = os.path.join(src, 'l2')
+    if os.path.isdir(hm):                # optional third pass: L2 hit / miss requests per kernel
+        hit, miss = counter_rows_raw(hm, 'TCC_HIT_sum'), counter_rows_raw(hm, 'TCC_MISS_sum')
+        for k in out:
+            if k in hit and k in miss and not k.startswith('_'):
+                h_, m_ = sum(hit[k]), sum(miss[k])
+                out[k]['l2_hit_rate'] = h_ / max(h_ + m_, 1.0)
     json.dump(out, open(f'profiles/{tag}_traffic.json', 'w'), indent=1)
     for k, v in out.items():
         if k.startswith('_'):
