@@ -188,6 +188,30 @@ def test_c3_properties():
     # the cube's truth comes from this package's own cubemodel (synth.make_fit): its
     # chi2 is checked against the oracle too, so that the property is not self-referential
     np.testing.assert_allclose(c_truth, orc.chi2_of(s, truth[0]), rtol=1e-9)
+    # dense sky on the same fit: a large broad-lined disk lights two thirds of the
+    # conv windows and overflows k_profile's sized launch into k_profile_rest (the launch was
+    # sized by the sparse batches above); one walker against the oracle, the batch for order
+    D = synth.walkers(40, workload='dense_disk')
+    gd = fit.chi2_batch(D)
+    assert np.array_equal(fit.chi2_batch(D[::-1])[::-1], gd)
+    np.testing.assert_allclose(gd[3], orc.chi2_of(s, D[3]), rtol=1e-9)
+    st = fit.engine.chi2_stats(D[3:4])
+    assert st['live_tiles'][0] > 0.5 * st['tiles'][0]            # it IS the dense case
+    fit.close()
+
+
+def test_c3_envelope_workload_vs_oracle():
+    """`envelope=True`, Ienv = 1 at C3 size: nothing is culled by radius (37 % of the conv
+    windows lit); one walker against the oracle, batch order bitwise."""
+    from slam_amd import synth
+    fit = synth.make_fit('C3', envelope=True)
+    E = synth.walkers(24, workload='envelope')
+    ge = fit.chi2_batch(E)
+    assert np.array_equal(fit.chi2_batch(E[::-1])[::-1], ge)
+    s = orc.make_setup(fit.x, fit.y, fit.v, fit.data, bmaj=fit.bmaj, bmin=fit.bmin, bpa=fit.bpa,
+                       sigma=fit.sigma, pa=2.0, incl=60.0, rmax=synth.RMAX, signmajor=1,
+                       signminor=1, envelope=True)
+    np.testing.assert_allclose(ge[7], orc.chi2_of(s, E[7]), rtol=1e-9)
     fit.close()
 
 
