@@ -47,6 +47,12 @@ def main():
     ap.add_argument('--dtype', default='f64', choices=['f64', 'f32', 'f32g'],
                     help="arithmetic of the hot path: f64 = the reference's (the headline); f32 = float "
                          "accumulation / beam passes with double geometry and index; f32g = float geometry too")
+    ap.add_argument('--beam-tol', type=float, default=0.0,
+                    help='opt-in truncated factorisation of a rotated beam (slamhip_desc::beam_tol); '
+                         '0 = exact (the default and the headline)')
+    ap.add_argument('--conv-mode', type=int, default=0, choices=[0, 2, 3],
+                    help='diagnostic: 2 = factorised beam even where direct taps are the default, '
+                         '3 = no folded regrid')
     ap.add_argument('--cpu-evals', type=int, default=1,
                     help='oracle evaluations timed for cpu_baseline (0 = skip)')
     ap.add_argument('--cpu-procs', type=int, default=-1,
@@ -94,8 +100,11 @@ def main():
         return
     t_start = time.perf_counter()
     fit = synth.make_fit(args.config, bpa=args.bpa, scaling=args.scaling,
-                         envelope=args.workload == 'envelope', precision=args.dtype)
+                         envelope=args.workload == 'envelope', precision=args.dtype,
+                         beam_tol=args.beam_tol)
     eng = fit.engine
+    if args.conv_mode:
+        eng.set_conv_mode(args.conv_mode)
     torch.cuda.synchronize()
     startup_s = time.perf_counter() - t_start   # per rank: synthetic cube, makegrid, context
     nw_total = args.walkers * world
@@ -291,7 +300,9 @@ def report(args, fit, eng, world, nw_total, dt, chi2, kern, psteps, counts):
         'data': 'synthetic',
         'config': {'workload': f'SYN-v1 {args.config} ({args.workload}, {args.dtype}): {nx}x{ny}x{nv} cube, '
                                f'{args.walkers} walkers per GPU per step, beam K={fit.gaussbeam.shape[0]} '
-                               f'bpa={args.bpa:g} (beam rank {eng.beam_rank})',
+                               f'bpa={args.bpa:g} (beam rank {eng.beam_rank})'
+                               + (f' beam_tol={args.beam_tol:g}' if args.beam_tol else '')
+                               + (f' conv_mode={args.conv_mode}' if args.conv_mode else ''),
                    'walkers_per_gpu': args.walkers, 'walkers_per_launch': eng.walkers_per_group,
                    'npix': eng.npix, 'nneed': n, 'nleaf': eng.nleaf,
                    'chi2_checksum': float(np.sum(chi2)),

@@ -92,6 +92,21 @@ typedef struct slamhip_desc {
                              * 1 and 2: scaling 'uniform' only; slamhip_cubemodel /
                              * _iconv apply the (double) dense beam to the
                              * single-precision Iunif. */
+  double beam_tol;          /* 0 (default) = the beam exactly as given (:329-335).
+                             * > 0: OPT-IN approximation for beams that are not an
+                             * outer product (bpa not a multiple of 90 deg): the
+                             * K x K kernel is replaced by its leading singular
+                             * triplets, as few as leave the dropped singular values
+                             * summing to <= beam_tol x the largest (a rotated
+                             * Gaussian's fall ~7x per term: 1e-7 keeps ~7 of 27),
+                             * and the fused kernel runs them as row + column passes
+                             * instead of K x K direct taps.  Model cube and chi2
+                             * then differ from the exact ones by ~beam_tol relative
+                             * (north_star allows 1e-5).  Used wherever the
+                             * factorised beam is (the batch entry points; the
+                             * 'mom0*' beam pass); slamhip_cubemodel / _iconv with
+                             * scaling 'uniform' keep the exact dense taps.  No
+                             * effect on separable beams.  Range [0, 1e-3]. */
 } slamhip_desc;
 
 typedef struct slamhip_ctx slamhip_ctx;
@@ -116,7 +131,9 @@ int slamhip_chi2_batch(slamhip_ctx* ctx, const double* params, int nw,
  * scratch set.  The library orders them on the device -- a call on another
  * stream than the previous one first waits (hipStreamWaitEvent) for the
  * previous call's last kernel -- but the HOST calls on one context must not
- * overlap: one thread at a time per context. */
+ * overlap: one thread at a time per context.  The one exception is
+ * slamhip_chi2_batch_static below: its scratch is shared by every context on
+ * the GPU and carries no event, so the library does NOT order its calls. */
 int slamhip_chi2_batch_dev(slamhip_ctx* ctx, const double* params_dev, int nw,
                            double* chi2_dev, void* stream);
 
@@ -133,7 +150,7 @@ int slamhip_chi2_batch_dev(slamhip_ctx* ctx, const double* params_dev, int nw,
  * copy into pinned host memory that slamhip_create allocated (a launch-sizing
  * hint for later groups; nothing waits for it).
  * Limits: scaling 'uniform' on the fused path only (mom0decon == NULL, conv
- * modes 0 and 2); a fit that needs more than the array for ONE walker
+ * modes 0, 2 and 3 -- every mode but the dense one); a fit that needs more than the array for ONE walker
  * (roughly 8*nv*nneed^2 + 64*2.5*npix^2 bytes: cubes up to about 256x256x64)
  * is rejected with SLAMHIP_ERR_NOMEM and a message naming both sizes.
  * All contexts on one GPU share the array and it keeps the last call's

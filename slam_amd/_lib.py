@@ -41,6 +41,7 @@ class SlamhipDesc(C.Structure):
         ('max_scratch_bytes', C.c_int64),
         ('mom0decon', _dp),
         ('precision', C.c_int32),
+        ('beam_tol', C.c_double),
     ]
 
 

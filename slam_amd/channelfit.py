@@ -64,9 +64,13 @@ class ChannelFit(ReadFits):
 
     def __init__(self, disk: bool = True, envelope: bool = False,
                  scaling: str = 'uniform', progressbar: bool = True,
-                 precision: str = 'f64'):
+                 precision: str = 'f64', beam_tol: float = 0.0):
         self.paramkeys = list(PARAMKEYS)
         self.precision = precision      # extension: 'f32' runs the likelihood in single precision
+        # extension, opt-in: a rotated (non-separable) beam may be replaced in the batched
+        # likelihood by a truncated factorisation, relative error ~beam_tol (slamhip_desc::beam_tol);
+        # 0 = the reference's beam exactly
+        self.beam_tol = float(beam_tol)
         self.disk = disk
         self.envelope = envelope
         self.scaling = scaling
@@ -242,7 +246,7 @@ class ChannelFit(ReadFits):
                 raise RuntimeError('call makegrid() first')
             self._engine = HipLikelihood(self.setup_dict(),
                                          max_scratch_bytes=self._max_scratch_bytes,
-                                         precision=self.precision)
+                                         precision=self.precision, beam_tol=self.beam_tol)
         return self._engine
 
     @engine.setter

@@ -28,7 +28,7 @@ class HipLikelihood:
     the x-flipped kernel).
     """
 
-    def __init__(self, setup, max_scratch_bytes=0, precision='f64'):
+    def __init__(self, setup, max_scratch_bytes=0, precision='f64', beam_tol=0.0):
         self._lib = _lib.load()
         self._ctx = C.c_void_p()
         if self._lib.slamhip_device_count() < 1:
@@ -78,6 +78,7 @@ class HipLikelihood:
             raise ValueError(f'precision must be one of {sorted(levels)}')
         self.precision = precision
         d.precision = levels[precision]
+        d.beam_tol = float(beam_tol)
         rc = self._lib.slamhip_create(C.byref(d), C.byref(self._ctx))
         if rc != 0:
             msg = self._errmsg()

@@ -34,7 +34,7 @@ def axes(N, NV):
 
 def make_fit(config='C3', bpa=0.0, seed=12345, N=None, NV=None, beam_px=None,
              verbose=False, max_scratch_bytes=0, scaling='uniform', envelope=False,
-             precision='f64'):
+             precision='f64', beam_tol=0.0):
     """Return a `ChannelFit` with a SYN-v1 cube loaded and `makegrid` done.
     The data are the same for every `scaling` and `envelope` (truth from the
     'uniform' disk-only model); `envelope=True` only switches the class flag
@@ -62,9 +62,9 @@ def make_fit(config='C3', bpa=0.0, seed=12345, N=None, NV=None, beam_px=None,
         rng = np.random.default_rng(seed)
         data = truth + rng.normal(0.0, SIGMA, truth.shape)
         fit.close()
-        if scaling != 'uniform' or envelope or precision != 'f64':
+        if scaling != 'uniform' or envelope or precision != 'f64' or beam_tol:
             fit = ChannelFit(scaling=scaling, envelope=envelope, progressbar=False,
-                             precision=precision)
+                             precision=precision, beam_tol=beam_tol)
         fit.set_cube(x, y, v, data, bmaj_px * dpix, bmin_px * dpix, bpa, SIGMA)
         fit.makegrid(cubefits=None, **kw)
     return fit

@@ -145,6 +145,29 @@ def test_chi2_batch_golden(case):
     assert np.array_equal(got, one)
 
 
+def test_truncated_beam_opt_in_golden():
+    """Golden configuration B (rotated beam, K = 17) with the opt-in `beam_tol`: the factorised
+    form (conv mode 2) then runs the truncated beam; chi2 against the REFERENCE's recorded
+    values within 1e-5 (this mode's tolerance; the default mode is checked at 1e-9 above)."""
+    from slam_amd import HipLikelihood
+    g = _golden.load('B')
+    s = orc.make_setup(**_golden.inputs(g))
+    names = _golden.vectors(g)
+    P = np.array([g[f'vec_{n}_p'] for n in names])
+    ref = np.array([float(g[f'vec_{n}_chi2']) for n in names])
+    with HipLikelihood(engine_setup(s), beam_tol=1e-5) as eng:
+        assert not eng.separable_beam
+        eng.set_conv_mode(2)
+        got = eng.chi2_batch(P)
+        np.testing.assert_allclose(got, ref, rtol=1e-5)
+        st = eng.chi2_stats(P)
+        for i, n in enumerate(names):
+            np.testing.assert_allclose(st['gf'][i], float(g[f'vec_{n}_gf']), rtol=1e-5)
+            np.testing.assert_allclose(st['ff'][i], float(g[f'vec_{n}_ff']), rtol=1e-5)
+    with HipLikelihood(engine_setup(s)) as eng:              # default: exact to 1e-9
+        np.testing.assert_allclose(eng.chi2_batch(P), ref, rtol=CHI2_TOL)
+
+
 def test_chi2_batch_vs_oracle_random(case):
     """Seeded random walkers in the example's prior box vs the oracle."""
     g, s, eng = case

@@ -164,6 +164,38 @@ def test_c2_rotated_beam_direct2d():
     fit.close()
 
 
+def test_c2_rotated_beam_truncated_factorisation():
+    """Opt-in `beam_tol` (slamhip_desc::beam_tol; no counterpart in the reference): a rotated
+    beam as its leading singular triplets.  Tolerance of THIS mode, written here: 1e-5 relative
+    on chi2 (north_star's fp64 bound); the default (beam_tol = 0) stays exact and is what every
+    other test checks at 1e-9."""
+    from slam_amd import synth
+    exact = synth.make_fit('C2', bpa=20.0)
+    P = synth.walkers(64)
+    ref = exact.chi2_batch(P)
+    s = orc.make_setup(exact.x, exact.y, exact.v, exact.data, bmaj=exact.bmaj, bmin=exact.bmin,
+                       bpa=exact.bpa, sigma=exact.sigma, pa=2.0, incl=60.0, rmax=synth.RMAX,
+                       signmajor=1, signminor=1)
+    want = np.array([orc.chi2_of(s, P[i]) for i in (0, 33)])
+    exact.close()
+    for tol, max_rank in ((1e-5, 5), (1e-7, 7)):
+        fit = synth.make_fit('C2', bpa=20.0, beam_tol=tol)
+        eng = fit.engine
+        if eng.beam_rank == 0:            # more terms than pay off: direct taps, i.e. exact
+            eng.set_conv_mode(2)          # ... the truncated factorisation is still what mode 2 runs
+        else:
+            assert 1 < eng.beam_rank <= max_rank
+        got = fit.chi2_batch(P)
+        np.testing.assert_allclose(got, ref, rtol=1e-5)
+        np.testing.assert_allclose(got[[0, 33]], want, rtol=1e-5)
+        assert np.max(np.abs(got / ref - 1)) < 10 * tol          # the singular tail bounds the error
+        assert not np.array_equal(got, ref)                        # and it IS the truncated beam
+        assert np.array_equal(fit.chi2_batch(P[::-1])[::-1], got)
+        fit.close()
+    with pytest.raises(Exception, match='beam_tol'):
+        synth.make_fit('C2', bpa=20.0, N=64, NV=8, beam_tol=0.5).engine
+
+
 def test_c3_properties():
     """BASELINE config 3 size (512x512x128).  Properties that hold at any size:
     walkers are independent (order / batch split do not matter, bitwise);

@@ -43,6 +43,19 @@ def test_static_entry_matches_allocating_entry():
     out4 = eng.chi2_batch_static_torch(P2)
     torch.cuda.synchronize()
     assert torch.equal(out4, ref2)
+    # conv mode 3 (conv tile + bilinear regrid for every walker, no folded taps) runs from the
+    # static scratch too; the dense mode 1 is refused
+    from slam_amd._lib import SlamhipError
+    eng.set_conv_mode(3)
+    ref5 = eng.chi2_batch_torch(P2)
+    out5 = eng.chi2_batch_static_torch(P2)
+    torch.cuda.synchronize()
+    assert torch.equal(out5, ref5)
+    np.testing.assert_allclose(ref5.cpu().numpy(), ref2.cpu().numpy(), rtol=1e-11)
+    eng.set_conv_mode(1)
+    with pytest.raises(SlamhipError, match='conv modes 0, 2 and 3'):
+        eng.chi2_batch_static_torch(P2)
+    eng.set_conv_mode(0)
     small.close()
     fit.close()
 
