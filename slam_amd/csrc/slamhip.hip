@@ -1319,16 +1319,28 @@ __device__ __forceinline__ void lds_barrier() {
 // taps, the C-wide window of `row` rotating through registers (one LDS read per tap);
 // the taps come through the scalar cache (block-uniform address).  kpad is a multiple of RU.
 template <int C, int RU, typename T>
-__device__ __forceinline__ void row_taps(const T* row, const T* __restrict__ wx, int kpad, T* res) {
+__device__ __forceinline__ void row_taps(const T* row, const T* __restrict__ wx, int kpad, bool tail4, T* res) {
   static_assert(RU % C == 0, "the window rotation must close over one unrolled step");
   T win[C];
 #pragma unroll
   for (int r = 0; r < C - 1; ++r) win[r] = row[r];
-  for (int u0 = 0; u0 < kpad; u0 += RU) {
+  // tail4 (block-uniform): the last RU / 2 of the kpad padded taps are zero padding (K + 1 <=
+  // kpad - 4, e.g. the folded 28 taps of a K = 27 beam in 32): the last step runs half its taps
+  const int kfull = tail4 ? kpad - RU : kpad;
+  for (int u0 = 0; u0 < kfull; u0 += RU) {
 #pragma unroll
     for (int qq = 0; qq < RU; ++qq) {
       win[(qq + C - 1) % C] = row[u0 + qq + C - 1];
       const T wgt = wx[u0 + qq];
+#pragma unroll
+      for (int r = 0; r < C; ++r) res[r] = fma(wgt, win[(r + qq) % C], res[r]);
+    }
+  }
+  if (tail4) {
+#pragma unroll
+    for (int qq = 0; qq < RU / 2; ++qq) {
+      win[(qq + C - 1) % C] = row[kfull + qq + C - 1];
+      const T wgt = wx[kfull + qq];
 #pragma unroll
       for (int r = 0; r < C; ++r) res[r] = fma(wgt, win[(r + qq) % C], res[r]);
     }
@@ -1347,7 +1359,13 @@ k_conv_chi2(FitK g, const T* __restrict__ iunif,
             double* __restrict__ partial, int kpad_arg, int nrank,
             const T* __restrict__ gxp, const T* __restrict__ gyp,
             const T* __restrict__ gbt,
-            const T* __restrict__ gxw, const T* __restrict__ gyw) {
+            const T* __restrict__ gxw, const T* __restrict__ gyw, int tail4_arg) {
+  // the last four of the kpad padded taps are padding in every tap set of this launch
+  // (K + 1 <= kpad - 4 with folded walkers, K <= kpad - 4 without): the last tap block of
+  // both passes / of the direct taps' rows runs half its length (K = 27: 28 of 32 taps;
+  // direct taps 166 instead of 175 us/eval at C3; the factorised form is not bound by its
+  // multiply-adds and stays at 31.6)
+  const bool tail4 = tail4_arg != 0;
   // the fixed-pitch factorised instance is only launched with 32 padded taps
   const int kpad = (PITCH != 0 && !DIRECT && sizeof(T) == 8) ? 32 : kpad_arg;
   // DIRECT (nrank == 0): the beam is not worth factorising (a rotated Gaussian
@@ -1649,7 +1667,8 @@ k_conv_chi2(FitK g, const T* __restrict__ iunif,
             const unsigned long long hi = w0 == 0 ? m1 : w0 == 1 ? m2 : w0 == 2 ? m3 : 0ull;
             bits = (lo >> sh) | (sh ? (hi << (64 - sh)) : 0ull);
           }
-          if (!(bits & ((1ull << (RB + R - 1)) - 1ull))) continue;
+          const bool half = tail4 && u0 == kpad - R;     // block-uniform: last tap rows are padding
+          if (!(bits & ((1ull << (half ? RB + R / 2 - 1 : RB + R - 1)) - 1ull))) continue;
           // three row pointers the compiler cannot relate: rows 3 apart lie more
           // than a ds_read2_b64's reach apart, so the reads stay single
           // ds_read_b64 (2 LDS cycles each; the paired form costs 8)
@@ -1661,10 +1680,20 @@ k_conv_chi2(FitK g, const T* __restrict__ iunif,
           const T* c2 = c0 + o2;
           T win[RB + R - 1];
 #pragma unroll
-          for (int r = 0; r < RB + R - 1; ++r)
+          for (int r = 0; r < RB + R / 2 - 1; ++r)
             win[r] = (r % 3 == 0 ? c0 : r % 3 == 1 ? c1 : c2)[(r / 3) * 3 * P];
 #pragma unroll
-          for (int qq = 0; qq < R; ++qq) {
+          for (int qq = 0; qq < R / 2; ++qq) {
+            const T wgt = wb[u0 + qq];
+#pragma unroll
+            for (int r = 0; r < RB; ++r) dacc[r] = fma(wgt, win[r + qq], dacc[r]);
+          }
+          if (half) continue;
+#pragma unroll
+          for (int r = RB + R / 2 - 1; r < RB + R - 1; ++r)
+            win[r] = (r % 3 == 0 ? c0 : r % 3 == 1 ? c1 : c2)[(r / 3) * 3 * P];
+#pragma unroll
+          for (int qq = R / 2; qq < R; ++qq) {
             const T wgt = wb[u0 + qq];
 #pragma unroll
             for (int r = 0; r < RB; ++r) dacc[r] = fma(wgt, win[r + qq], dacc[r]);
@@ -1696,9 +1725,9 @@ k_conv_chi2(FitK g, const T* __restrict__ iunif,
         const int l = lane & (63 >> sh);
         if (l < m) {
           const T* row = tile + s_rowlist[q * 64 + l] * P + wv * R + (lane >> (6 - sh)) * (R >> sh);
-          if (sh == 0) row_taps<R, R>(row, wxr, kpad, res[q]);
-          else if (sh == 1) row_taps<R / 2, R>(row, wxr, kpad, res[q]);
-          else row_taps<R / 4, R>(row, wxr, kpad, res[q]);
+          if (sh == 0) row_taps<R, R>(row, wxr, kpad, tail4, res[q]);
+          else if (sh == 1) row_taps<R / 2, R>(row, wxr, kpad, tail4, res[q]);
+          else row_taps<R / 4, R>(row, wxr, kpad, tail4, res[q]);
         }
       }
       STAMP(3);
@@ -1756,6 +1785,20 @@ k_conv_chi2(FitK g, const T* __restrict__ iunif,
             const unsigned long long lo = w0 == 0 ? m0 : w0 == 1 ? m1 : w0 == 2 ? m2 : m3;
             const unsigned long long hi = w0 == 0 ? m1 : w0 == 1 ? m2 : w0 == 2 ? m3 : 0ull;
             bits = (lo >> sh) | (sh ? (hi << (64 - sh)) : 0ull);
+          }
+          if (tail4 && u0 == kpad - R) {
+            // half block: R / 2 taps over the R + R / 2 - 1 rows they reach
+            if (!(bits & ((1ull << (R + R / 2 - 1)) - 1ull))) continue;
+            T win[R + R / 2 - 1];
+#pragma unroll
+            for (int r = 0; r < R + R / 2 - 1; ++r) win[r] = col[(u0 + r) * P2];
+#pragma unroll
+            for (int qq = 0; qq < R / 2; ++qq) {
+              const T wgt = wyr[u0 + qq];
+#pragma unroll
+              for (int r = 0; r < R; ++r) acc[r] = fma(wgt, win[r + qq], acc[r]);
+            }
+            continue;
           }
           if (!(bits & ((1ull << (2 * R - 1)) - 1ull))) continue;
           T win[2 * R - 1];
@@ -3260,11 +3303,14 @@ void launch_fused(slamhip_ctx* c, Scratch& S, int fz_rank, hipStream_t st, const
                   const T* ft, const T* gxw, const T* gyw) {
   dim3 gz(fz_rank ? c->persist_blocks : c->persist_direct, 1, 1);
   const size_t fz_lds = fz_rank ? c->fz_lds : c->fz_lds_direct;
+  // the taps any window of this launch uses: K, or K + 1 where the regrid is folded in
+  const int ntap = c->k.kbeam + ((fz_rank == 1 && c->k.fold) ? 1 : 0);
+  const int tail4 = ntap <= c->kpad - CONV_R / 2 ? 1 : 0;
 #define SLAM_FUSED_M(TY_, MR_, DIR_, PITCH_, MULTI_)                                               \
   hipLaunchKernelGGL((k_conv_chi2<TY_, MR_, DIR_, PITCH_, T, MULTI_>), gz, dim3(CV_NT), fz_lds, st, \
                      c->k, (const T*)S.iunif, S.cellx, S.fracx, S.celly, S.fracy, S.livelist,       \
                      S.livecount, (int)c->fz_grid.x, (int)c->fz_grid.y, S.partial, c->kpad,         \
-                     fz_rank, gx, gy, ft, gxw, gyw)
+                     fz_rank, gx, gy, ft, gxw, gyw, tail4)
 #define SLAM_FUSED(TY_, MR_, DIR_, PITCH_) SLAM_FUSED_M(TY_, MR_, DIR_, PITCH_, true)
 #define SLAM_FUSED_SEP(TY_, MR_) \
   do { if (fz_rank == 1) SLAM_FUSED_M(TY_, MR_, false, 0, false); else SLAM_FUSED(TY_, MR_, false, 0); } while (0)
