@@ -1646,7 +1646,7 @@ k_conv_chi2(FitK g, const T* __restrict__ iunif,
     // direct taps: wave <-> (block of RB output rows, half of the tap columns);
     // the two halves are added through LDS afterwards
     constexpr int RB = TY == 64 ? 2 * R : R;
-    static_assert(TY / RB == CV_NW / 2, "four row blocks, two tap-column halves");
+    static_assert(!DIRECT || TY / RB == CV_NW / 2, "direct taps: four row blocks, two tap-column halves");
     const int rb = wv % (TY / RB), tapset = wv / (TY / RB);
     T dacc[DIRECT ? RB : 1];
     if (DIRECT) {
@@ -3287,6 +3287,7 @@ const void* fused_instance(int variant, bool direct, bool fixed, bool multi = tr
   if (!direct && !multi)
     return variant == 0 ? (const void*)k_conv_chi2<64, 2, false, 0, T, false>
          : variant == 1 ? (const void*)k_conv_chi2<64, 3, false, 0, T, false>
+         : variant == 3 ? (const void*)k_conv_chi2<48, 2, false, 0, T, false>
                         : (const void*)k_conv_chi2<32, 2, false, 0, T, false>;
   if (!direct)
     return variant == 0 ? (const void*)k_conv_chi2<64, 2, false, 0, T>
@@ -3322,6 +3323,7 @@ void launch_fused(slamhip_ctx* c, Scratch& S, int fz_rank, hipStream_t st, const
       else SLAM_FUSED(64, 2, true, 0);
       break;
     case 1: if (fz_rank) SLAM_FUSED_SEP(64, 3); else SLAM_FUSED(64, 3, true, 0); break;
+    case 3: SLAM_FUSED_M(48, 2, false, 0, false); break;      // one-term beams only (slamhip_create)
     default: if (fz_rank) SLAM_FUSED_SEP(32, 2); else SLAM_FUSED(32, 2, true, 0); break;
   }
 #undef SLAM_FUSED_SEP
@@ -3565,6 +3567,13 @@ int slamhip_create(const slamhip_desc* d, slamhip_ctx** out) {
   };
   c->sep_variant = pick_variant(sizeof(double));
   c->fz_variant = pick_variant(c->item);
+  // Large one-term beams (K = 77 in double: BASELINE config 4) fit neither 64-row tile; between
+  // them and the 32-row one a 48-row window (6 of the 8 waves take the column pass) has 2.6 halo +
+  // output rows in its row pass per output row instead of 3.4.
+  if (c->fz_variant == 2 && c->nrank == 1 &&
+      fz_tile_bytes(48, c->kpad) / sizeof(double) * c->item + 2 * c->kpad * c->item <= 156 * 1024 &&
+      48 + c->kpad - 1 <= 128)
+    c->fz_variant = 3;
   if (c->sep_variant >= 0) c->sep_lds = sep_lds_bytes(c->sep_variant == 2 ? 32 : 64, c->kpad);
   c->c2d_lds = (size_t)(C2_TY + K - 1) * ((C2_TX + K - 1) | 1) * sizeof(double);
   if (c->sep_lds > 48 * 1024) {   // opt in to large dynamic LDS for the chosen variant only
@@ -3573,7 +3582,7 @@ int slamhip_create(const slamhip_desc* d, slamhip_ctx** out) {
                                          : (const void*)k_conv_sep<32, 4>;
     HIP_TRY(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->sep_lds));
   }
-  const size_t fz_ty = c->fz_variant == 2 ? 32 : 64;
+  const size_t fz_ty = c->fz_variant == 2 ? 32 : c->fz_variant == 3 ? 48 : 64;
   const size_t fz_tile = c->fz_variant < 0 ? 0 : fz_tile_bytes((int)fz_ty, c->kpad) / sizeof(double) * c->item;
   c->fz_lds = fz_tile + 2 * (size_t)std::max(c->nrank, 1) * c->kpad * c->item;
   if (c->nrank > 1 && c->fz_variant >= 0) {
@@ -3732,7 +3741,7 @@ int slamhip_create(const slamhip_desc* d, slamhip_ctx** out) {
   if (d->mom0decon && (rc = dev_alloc(c, &c->d_rowflag, W * (size_t)k.nv * k.ny * nseg))) return rc;
   {
     // a conv window must not span more occupancy bytes than its LDS table holds
-    const int ty = c->fz_variant == 2 ? 32 : 64;
+    const int ty = c->fz_variant == 2 ? 32 : c->fz_variant == 3 ? 48 : 64;
     const int spanx = (CONV_TX + K - 2) / PT_X + 2, spany = (ty + K - 2) / PT_Y + 2;
     if (c->fused && (spanx * spany > FLAG_MAX || spanx > 255 || spany > 255)) c->fused = 0;   // descriptor ids pack (fy, fx) in 8 bits each
     if ((int)(c->fz_grid.x + c->fz_grid.y) > PREP_TILES) c->fused = 0;
