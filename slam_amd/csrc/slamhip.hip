@@ -1301,6 +1301,9 @@ k_compact(FitK g, const unsigned char* __restrict__ winflag, int total,
 // [y0, y0+TY-1) with x0 = bx*(TX-1), y0 = by*(TY-1).
 constexpr int CV_NT = 512;                   // threads per workgroup
 constexpr int CV_NW = CV_NT / 64;            // waves
+#ifndef CV_NSB
+#define CV_NSB 7                             // staged tiles per wave held in registers
+#endif
 #ifndef CV_MINW_F32
 // waves per SIMD the float instances are compiled for: their tile is half the size, three
 // workgroups fit a CU's LDS, and 80 VGPRs (44 B of scratch in the hot instance) buy that
@@ -1377,7 +1380,7 @@ k_conv_chi2(FitK g, const T* __restrict__ iunif,
   constexpr int TX = CONV_TX, R = CONV_R, PC = TX + 1, P2 = TX + 1;
   constexpr bool direct = DIRECT;
   constexpr int NRQ = (TY - 1 + CV_NW - 1) / CV_NW;         // regrid rows per wave
-  constexpr int NSB = 7;                                    // staged tiles per wave held in registers
+  constexpr int NSB = CV_NSB;                                  // staged tiles per wave held in registers
   __shared__ unsigned char s_rowlist[256];
   __shared__ double sg[CV_NW], sf[CV_NW];
   const int K = g.kbeam, ng = g.ngauss, n = g.nneed;
