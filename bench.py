@@ -50,9 +50,9 @@ def main():
     ap.add_argument('--beam-tol', type=float, default=0.0,
                     help='opt-in truncated factorisation of a rotated beam (slamhip_desc::beam_tol); '
                          '0 = exact (the default and the headline)')
-    ap.add_argument('--conv-mode', type=int, default=0, choices=[0, 2, 3],
+    ap.add_argument('--conv-mode', type=int, default=0, choices=[0, 2, 3, 4],
                     help='diagnostic: 2 = factorised beam even where direct taps are the default, '
-                         '3 = no folded regrid')
+                         '3 = no folded regrid, 4 = k_conv_chi2 where k_conv_rows is the default')
     ap.add_argument('--cpu-evals', type=int, default=1,
                     help='oracle evaluations timed for cpu_baseline (0 = skip)')
     ap.add_argument('--cpu-procs', type=int, default=-1,

@@ -227,7 +227,10 @@ int slamhip_beam_rank(slamhip_ctx* ctx);
  * direct taps, see slamhip_beam_rank), 1 = force the dense, non-fused direct
  * 2-D path, 2 = fused kernel with the factorised beam even where 0 would take
  * direct taps, 3 = fused kernel without folding the regrid into the beam taps
- * (every walker keeps the convolved tile + bilinear regrid) (cross-checks). */
+ * (every walker keeps the convolved tile + bilinear regrid), 4 = as 0 but the
+ * phase-by-phase window kernel (k_conv_chi2) where 0 runs the row-owning one
+ * (k_conv_rows: one-term beams of 25..32 padded taps in double); both give
+ * bitwise the same chi2 (cross-checks). */
 int slamhip_set_conv_mode(slamhip_ctx* ctx, int mode);
 
 /* Measurement aid (no counterpart in the reference): between _begin and _end

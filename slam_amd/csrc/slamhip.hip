@@ -1928,6 +1928,331 @@ k_conv_chi2(FitK g, const T* __restrict__ iunif,
 #undef STAMP
 }
 
+// k_conv_rows: k_conv_chi2's one-term, K + 1 <= 32 taps, 64-row-window case with the window's
+// ROWS OWNED BY WAVES.  k_conv_chi2 walks a window in phases that every wave must finish before
+// any wave may go on (zero the tile | stage the tiles | row pass | write the intermediate | column
+// pass | sums: five barriers), and the counters show its waves waiting, not computing.  Here a wave
+// owns groups of four image rows (group q of the window belongs to wave (q + q/8) mod 8, so that
+// the rows it handles together differ mod 8 and its LDS reads do not collide): it zeroes THEM,
+// asks for the halves of the occupied tiles that lie on THEM (a quarter wave per row, 16 bytes per
+// lane), stores them, runs the row pass over those of them that hold emission (a lane = one row x
+// one block of 8 output columns) and writes the results IN PLACE over the rows it has just read --
+// nothing any other wave touches, so none of this needs a barrier.  One barrier before the column
+// pass (which reads every wave's rows) and one after the sums are left.  Same arithmetic, same
+// order of operations per output as k_conv_chi2's fixed-pitch instance: chi2 is bitwise the same.
+template <typename T>
+__global__ void __launch_bounds__(CV_NT, 4)
+k_conv_rows(FitK g, const T* __restrict__ iunif,
+            const int* __restrict__ cellx, const double* __restrict__ fracx,
+            const int* __restrict__ celly, const double* __restrict__ fracy,
+            const WinDesc* __restrict__ list, int* __restrict__ count, int wnx, int wny,
+            double* __restrict__ partial,
+            const T* __restrict__ gxp, const T* __restrict__ gyp,
+            const T* __restrict__ gxw, const T* __restrict__ gyw, int tail4_arg) {
+  extern __shared__ unsigned char lds_raw[];
+  T* const lds = reinterpret_cast<T*>(lds_raw);
+  using T2 = typename Real<T>::vec2;
+  constexpr int TY = 64, TX = CONV_TX, R = CONV_R, PC = TX + 1, KP = 32, P = SEP_PITCH;
+  constexpr int ROWS = TY + KP - 1;                         // 95 window rows incl. halo and tap padding
+  constexpr int NRQ = (TY - 1 + CV_NW - 1) / CV_NW;         // regrid rows per wave
+  constexpr int NG = 4;                                     // row groups a wave can own (25 groups, 8 waves)
+  static_assert(P > TX + KP - 1 + 1, "room for the column shift");
+  __shared__ unsigned char s_rowlist[CV_NW][16];
+  __shared__ double sg[CV_NW], sf[CV_NW];
+  const bool tail4 = tail4_arg != 0;
+  const int K = g.kbeam, ng = g.ngauss, n = g.nneed;
+  const int vrows = TY + K - 1, vcols = TX + K - 1;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nlive = *count;
+  constexpr int DW = sizeof(WinDesc) / 4;
+  __shared__ __attribute__((aligned(16))) unsigned s_desc[2][DW];
+  __shared__ int s_ticket;
+  int* queue = count + 1;
+  if ((int)blockIdx.x >= nlive) return;                     // whole workgroup
+  if (tid < DW) s_desc[0][tid] = reinterpret_cast<const unsigned*>(&list[blockIdx.x])[tid];
+  constexpr int TICKET_B = 4;
+  if (tid == 0) s_ticket = (int)gridDim.x + atomicAdd(queue, TICKET_B);
+  __syncthreads();
+  int nxt = __builtin_amdgcn_readfirstlane(s_ticket);
+  int held = TICKET_B - 1;
+  int par = 0;
+  // this lane in the staging (a quarter wave per row of a group, 16 bytes per lane) and in the
+  // row pass (half waves take column blocks 0-3 / 4-7, eight row slots x four blocks each)
+  const int srow = lane >> 4, scol = (lane & 15) * 2;
+  const int pslot = (lane >> 2) & 7, pcb = ((lane >> 5) << 2) | (lane & 3);
+  for (int it = blockIdx.x; it < nlive; par ^= 1) {
+    unsigned nextw = 0;
+    if (tid < DW && nxt < nlive)
+      nextw = reinterpret_cast<const unsigned*>(&list[nxt])[tid];
+    int fut = nlive;
+    if (held == 0 && tid == 0 && nxt < nlive) fut = (int)gridDim.x + atomicAdd(queue, TICKET_B);
+    const unsigned hd = s_desc[par][lane & 15];
+    const unsigned ocv = s_desc[par][44 + (lane & 1)];      // occupancy bitmap, first word (<= 52 tiles here)
+    static_assert(offsetof(WinDesc, occ) == 44 * 4, "descriptor layout");
+    auto head = [&](int i) { return (int)__builtin_amdgcn_readlane(hd, i); };
+    const int e = head(0);
+    const int z = head(6);
+    const int tb = head(7);
+    const int tby = (tb >> 8) & 0xff, tbx = tb & 0xff;
+    const int wi = (int)((unsigned)tb >> 16), k = z - wi * g.nv;
+    const T* src = iunif + (long long)z * n * n;
+    const int x0 = tbx * (TX - 1), y0 = tby * (TY - 1);
+    const int wx0 = x0 - ng, wy0 = y0 - ng;
+    const int ftx0 = max(wx0, 0) / PT_X, fty0 = max(wy0, 0) / PT_Y;
+    const int fnx = min(wx0 + vcols - 1, n - 1) / PT_X - ftx0 + 1;
+    const unsigned long long occ = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(ocv, 1) << 32) |
+                                   (unsigned)__builtin_amdgcn_readlane(ocv, 0);
+    const int fxw = head(2), fyw = head(4);
+    const bool fold_w = fxw < 0;                            // block-uniform
+    const int fja = (fxw >> 8) & 255, fjb = (fxw >> 16) & 255;
+    const int pixx = (fold_w && lane >= fja && lane < fjb) ? head(1) + ((fxw & 1) ? lane : -lane) : -1;
+    const int woff = wx0 & 1;
+    T* tile = lds + woff;
+    auto head64 = [&](int i) {
+      return ((unsigned long long)(unsigned)head(i + 1) << 32) | (unsigned)head(i);
+    };
+    const unsigned long long m0 = head64(8), m1 = head64(10);
+
+    // -- 0. this wave's row groups: group q holds window rows 4q - a .. 4q - a + 3, image rows
+    //       4 (mq + q) ..; its tiles are the half `Q & 1` of tile row Q >> 1
+    const int a = wy0 & 3, mq = wy0 >> 2;                   // floor semantics for negative wy0 too
+    T2 sv[NG][4];
+    unsigned sok = 0u;                                      // bit 4 gi + fx: this lane holds a pair there
+    unsigned m16 = 0u;                                      // bit 4 gi + i: that owned row holds emission
+#pragma unroll
+    for (int gi = 0; gi < NG; ++gi) {
+      const int q = 8 * gi + ((wv - gi) & 7);
+      const int rb = 4 * q - a;                             // first window row of the group
+      const int Q = mq + q;
+      const int fy = (Q >> 1) - fty0;
+      // four mask bits from window row rb on (rows < 0 are not lit)
+      {
+        const int sh = rb < 0 ? 0 : rb;
+        const unsigned long long lo = sh < 64 ? m0 : m1, hi = sh < 64 ? m1 : 0ull;
+        const int s6 = sh & 63;
+        unsigned long long bits = (lo >> s6) | (s6 ? (hi << (64 - s6)) : 0ull);
+        if (rb < 0) bits <<= -rb;
+        if (rb < ROWS) m16 |= (unsigned)(bits & 15ull) << (4 * gi);
+      }
+#pragma unroll
+      for (int fx = 0; fx < 4; ++fx) {
+        sv[gi][fx] = Real<T>::make2((T)0, (T)0);
+        const bool present = rb < vrows && rb + 4 > 0 && Q >= 0 && fy >= 0 && fx < fnx &&
+                             ((occ >> (fy * fnx + fx)) & 1ull);         // wave-uniform
+        if (present) {
+          const int irow = 4 * Q + srow, icol = (ftx0 + fx) * PT_X + scol;
+          const int r = rb + srow, cc = icol - wx0;
+          if (r >= 0 && r < vrows && irow < n && icol < n && cc >= -woff && cc < vcols) {
+            sv[gi][fx] = *reinterpret_cast<const T2*>(src + (long long)irow * n + icol);
+            sok |= 1u << (4 * gi + fx);
+          }
+        }
+      }
+    }
+    const double* dat = g.data + (long long)k * g.ny * g.nx;
+    const int ixa = head(1), ixb = head(2);
+    const int jya = head(3), jyb = head(4);
+    const int ix = ixa + lane;
+    int i1 = -1;
+    double t1 = 0.0;
+    double dv[NRQ], t0q[NRQ];
+    int i0q[NRQ];
+
+    // -- 1. zero the owned rows (all 95: the column pass reads the padded ones against zero taps),
+    //       list those with emission
+#pragma unroll
+    for (int gi = 0; gi < NG; ++gi) {
+      const int rb = 4 * (8 * gi + ((wv - gi) & 7)) - a;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = rb + i;
+        if (r < 0 || r >= ROWS) continue;                   // wave-uniform
+        T* rowp = lds + r * P;
+        rowp[lane] = 0;
+        if (lane < P - 64) rowp[64 + lane] = 0;
+      }
+    }
+    const int nown = __popc(m16);
+    if (lane < 16 && ((m16 >> lane) & 1u)) {
+      const int gi = lane >> 2;
+      s_rowlist[wv][__popc(m16 & ((1u << lane) - 1u))] =
+          (unsigned char)(4 * (8 * gi + ((wv - gi) & 7)) - a + (lane & 3));
+    }
+
+    // -- 2. the tile halves on the owned rows
+#pragma unroll
+    for (int gi = 0; gi < NG; ++gi) {
+      const int rb = 4 * (8 * gi + ((wv - gi) & 7)) - a;
+#pragma unroll
+      for (int fx = 0; fx < 4; ++fx) {
+        if ((sok >> (4 * gi + fx)) & 1u) {
+          T* o = tile + (rb + srow) * P + ((ftx0 + fx) * PT_X + scol - wx0);
+          o[0] = sv[gi][fx].x;
+          o[1] = sv[gi][fx].y;
+        }
+      }
+    }
+    double fdv[R];
+    unsigned fvalid = 0u;
+#pragma unroll
+    for (int r = 0; r < R; ++r) fdv[r] = 0.0;
+    if (fold_w) {
+      const int ya = (fyw >> 8) & 255, yb = (fyw >> 16) & 255;
+      const int rlo = max(ya - wv * R, 0), rhi = min(yb - wv * R, R);
+      if (rhi > rlo) fvalid = ((1u << rhi) - 1u) & ~((1u << rlo) - 1u);
+      const long long step = (fyw & 1) ? (long long)g.nx : -(long long)g.nx;
+      const double* rowp = dat + (long long)(head(3) + ((fyw & 1) ? wv * R : -(wv * R))) * g.nx;
+      if (pixx >= 0) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          if ((fvalid >> r) & 1u) fdv[r] = rowp[pixx];      // wave-uniform test
+          rowp += step;
+        }
+      }
+    }
+
+    // -- 3. row pass over the owned rows with emission, results in place (this wave's rows only)
+    const T* __restrict__ wxr = fold_w ? gxw + (long long)wi * KP : gxp;
+    const T* __restrict__ wyr = fold_w ? gyw + (long long)wi * KP : gyp;
+    T res[2][R];
+    int rrow[2];
+#pragma unroll
+    for (int rd = 0; rd < 2; ++rd) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) res[rd][r] = 0;
+      rrow[rd] = -1;
+      if (rd * 8 < nown) {                                  // wave-uniform
+        const int slot = rd * 8 + pslot;
+        if (slot < nown) {
+          rrow[rd] = s_rowlist[wv][slot];
+          row_taps<R, R>(tile + rrow[rd] * P + pcb * R, wxr, KP, tail4, res[rd]);
+        }
+      }
+    }
+#pragma unroll
+    for (int rd = 0; rd < 2; ++rd) {
+      if (rrow[rd] >= 0) {
+        T* o = tile + rrow[rd] * P + pcb * R;
+#pragma unroll
+        for (int r = 0; r < R; ++r) o[r] = res[rd][r];
+      }
+    }
+    lds_barrier();                                          // every wave's rows hold the intermediate
+
+    // -- 4. column pass: out[y][x] = sum_u gyf[u] tmp[y + u][x]  (lanes <-> x, waves <-> 8 rows)
+    T acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = 0;
+    {
+      const T* col = tile + (wv * R) * P + lane;
+      const unsigned long long mcol = wv ? (m0 >> (wv * R)) | (m1 << (64 - wv * R)) : m0;
+      for (int u0 = 0; u0 < KP; u0 += R) {
+        const unsigned long long bits = mcol >> u0;
+        if (tail4 && u0 == KP - R) {
+          if (!(bits & ((1ull << (R + R / 2 - 1)) - 1ull))) continue;
+          T win[R + R / 2 - 1];
+#pragma unroll
+          for (int r = 0; r < R + R / 2 - 1; ++r) win[r] = col[(u0 + r) * P];
+#pragma unroll
+          for (int qq = 0; qq < R / 2; ++qq) {
+            const T wgt = wyr[u0 + qq];
+#pragma unroll
+            for (int r = 0; r < R; ++r) acc[r] = fma(wgt, win[r + qq], acc[r]);
+          }
+          continue;
+        }
+        if (!(bits & ((1ull << (2 * R - 1)) - 1ull))) continue;
+        T win[2 * R - 1];
+#pragma unroll
+        for (int r = 0; r < 2 * R - 1; ++r) win[r] = col[(u0 + r) * P];
+#pragma unroll
+        for (int qq = 0; qq < R; ++qq) {
+          const T wgt = wyr[u0 + qq];
+#pragma unroll
+          for (int r = 0; r < R; ++r) acc[r] = fma(wgt, win[r + qq], acc[r]);
+        }
+      }
+    }
+    double gf = 0.0, ff = 0.0;
+    if (fold_w) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const double av = (pixx >= 0 && ((fvalid >> r) & 1u)) ? (double)acc[r] : 0.0;
+        gf = fma(av, fdv[r], gf);
+        ff = fma(av, av, ff);
+      }
+    } else {
+      // conv tile + bilinear regrid, as k_conv_chi2
+      if (ix < ixb) {
+        i1 = cellx[(long long)wi * g.nx + ix] - x0;
+        t1 = fracx[(long long)wi * g.nx + ix];
+      }
+#pragma unroll
+      for (int q = 0; q < NRQ; ++q) {
+        const int jy = jya + wv + CV_NW * q;
+        const bool rowin = jy < jyb;
+        i0q[q] = rowin ? celly[(long long)wi * g.ny + jy] - y0 : -1;
+        t0q[q] = rowin ? fracy[(long long)wi * g.ny + jy] : 0.0;
+        dv[q] = (ix < ixb && rowin) ? dat[(long long)jy * g.nx + ix] : 0.0;
+      }
+      const bool xown = i1 >= 0 && i1 < TX - 1;
+      lds_barrier();                                        // column pass done reading LDS
+#pragma unroll
+      for (int r = 0; r < R; ++r) lds[(wv * R + r) * PC + lane] = acc[r];
+      lds_barrier();
+#pragma unroll
+      for (int q = 0; q < NRQ; ++q) {
+        const int jy = jya + wv + CV_NW * q;
+        if (jy < jyb) {
+          const int i0 = i0q[q];
+          if (xown && i0 >= 0 && i0 < TY - 1) {
+            const double t0 = t0q[q];
+            const T* c = lds + i0 * PC + i1;
+            const double v00 = c[0], v01 = c[1], v10 = c[PC], v11 = c[PC + 1];
+            const double val = v00 * (1 - t0) * (1 - t1) + v01 * (1 - t0) * t1 +
+                               v10 * t0 * (1 - t1) + v11 * t0 * t1;
+            gf = fma(val, dv[q], gf);
+            ff = fma(val, val, ff);
+          }
+        }
+      }
+      for (int ix2 = ix; ix2 < ixb; ix2 += 64) {
+        const int i1b = cellx[(long long)wi * g.nx + ix2] - x0;
+        if (i1b < 0 || i1b >= TX - 1) continue;
+        const double t1b = fracx[(long long)wi * g.nx + ix2];
+        for (int jy = jya + wv + (ix2 == ix ? CV_NW * NRQ : 0); jy < jyb; jy += CV_NW) {
+          const int i0 = celly[(long long)wi * g.ny + jy] - y0;
+          if (i0 < 0 || i0 >= TY - 1) continue;
+          const double t0 = fracy[(long long)wi * g.ny + jy];
+          const T* c = lds + i0 * PC + i1b;
+          const double val = (double)c[0] * (1 - t0) * (1 - t1b) + (double)c[1] * (1 - t0) * t1b +
+                             (double)c[PC] * t0 * (1 - t1b) + (double)c[PC + 1] * t0 * t1b;
+          gf = fma(val, dat[(long long)jy * g.nx + ix2], gf);
+          ff = fma(val, val, ff);
+        }
+      }
+    }
+    gf = wave_sum_dpp(gf);
+    ff = wave_sum_dpp(ff);
+    if (lane == 0) { sg[wv] = gf; sf[wv] = ff; }
+    if (tid < DW) s_desc[par ^ 1][tid] = nextw;
+    if (tid == 0) s_ticket = fut;
+    lds_barrier();                                          // also: every wave is done with this window's rows
+    if (tid == 0) {
+      double av = 0.0, b2 = 0.0;
+#pragma unroll
+      for (int q = 0; q < CV_NW; ++q) { av += sg[q]; b2 += sf[q]; }
+      partial[3 * (long long)e] = av;
+      partial[3 * (long long)e + 1] = b2;
+      partial[3 * (long long)e + 2] = 1.0;
+    }
+    it = nxt;
+    if (held > 0) { nxt = nxt + 1; --held; }
+    else { nxt = __builtin_amdgcn_readfirstlane(s_ticket); held = TICKET_B - 1; }
+  }
+}
+
 // k_conv_2d: general (rotated) beam, direct K x K taps on an LDS tile.
 constexpr int C2_TX = 64, C2_TY = 16, C2_RY = 4;
 __global__ void __launch_bounds__(256)
@@ -3320,7 +3645,11 @@ void launch_fused(slamhip_ctx* c, Scratch& S, int fz_rank, hipStream_t st, const
   do { if (fz_rank == 1) SLAM_FUSED_M(TY_, MR_, false, 0, false); else SLAM_FUSED(TY_, MR_, false, 0); } while (0)
   switch (c->fz_variant) {
     case 0:
-      if (fz_rank == 1 && c->sep_fixed) SLAM_FUSED_M(64, 2, false, SEP_PITCH, false);
+      if (fz_rank == 1 && c->sep_fixed && sizeof(T) == 8 && c->conv_mode != 4)
+        hipLaunchKernelGGL((k_conv_rows<T>), gz, dim3(CV_NT), fz_lds, st, c->k, (const T*)S.iunif, S.cellx,
+                           S.fracx, S.celly, S.fracy, S.livelist, S.livecount, (int)c->fz_grid.x,
+                           (int)c->fz_grid.y, S.partial, gx, gy, gxw, gyw, tail4);
+      else if (fz_rank == 1 && c->sep_fixed) SLAM_FUSED_M(64, 2, false, SEP_PITCH, false);
       else if (fz_rank) SLAM_FUSED_SEP(64, 2);
       else if (c->direct_fixed) SLAM_FUSED(64, 2, true, DIRECT_PITCH);
       else SLAM_FUSED(64, 2, true, 0);
@@ -3619,6 +3948,9 @@ int slamhip_create(const slamhip_desc* d, slamhip_ctx** out) {
     if (c->nrank >= 1 && c->sep_fixed) {
       const void* f2 = c->f32 ? fused_instance<float>(0, false, true, false) : fused_instance<double>(0, false, true, false);
       HIP_TRY(c, hipFuncSetAttribute(f2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->fz_lds));
+      if (!c->f32)
+        HIP_TRY(c, hipFuncSetAttribute((const void*)k_conv_rows<double>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->fz_lds));
     }
     if (c->nrank >= 1) {
       HIP_TRY(c, hipFuncSetAttribute(fz, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->fz_lds));
@@ -3878,7 +4210,7 @@ int slamhip_beam_rank(slamhip_ctx* c) {
 }
 
 int slamhip_set_conv_mode(slamhip_ctx* c, int mode) {
-  if (!c || mode < 0 || mode > 3) return SLAMHIP_ERR_ARG;
+  if (!c || mode < 0 || mode > 4) return SLAMHIP_ERR_ARG;
   if (mode == 1 && c->f32)
     return fail(c, SLAMHIP_ERR_ARG, "conv mode 1 (dense, double) is not available at precision 1 (float)");
   if (mode == 1 && !c->k.mom0decon) {

@@ -394,6 +394,29 @@ def test_folded_regrid_equals_conv_tile_plus_regrid(c2):
     assert np.array_equal(eng.chi2_stats(P)['chi2'], folded['chi2'])  # and back
 
 
+def test_row_owning_kernel_equals_phase_kernel(c2):
+    """k_conv_rows (waves own the window's rows: two barriers per window) is the default for
+    one-term beams of 25..32 padded taps in double; conv mode 4 runs k_conv_chi2's fixed-pitch
+    instance on the same windows.  Same operations in the same order per output: bitwise equal,
+    with the folded regrid and without (mode 3), on sparse and dense sky."""
+    from slam_amd import synth
+    eng = c2.engine
+    P = np.concatenate([synth.walkers(48), synth.walkers(16, workload='dense_disk')])
+    P[5, 8:10] = (3.3, -7.1)                    # a shifted walker: observed / model grids out of step
+    got = c2.chi2_batch(P)
+    st = eng.chi2_stats(P)
+    eng.set_conv_mode(4)
+    old = c2.chi2_batch(P)
+    st4 = eng.chi2_stats(P)
+    eng.set_conv_mode(3)
+    unf = c2.chi2_batch(P)                      # rows kernel, conv tile + bilinear regrid
+    eng.set_conv_mode(0)
+    assert np.array_equal(got, old)
+    assert np.array_equal(st['gf'], st4['gf']) and np.array_equal(st['ff'], st4['ff'])
+    np.testing.assert_allclose(unf, got, rtol=1e-11)
+    assert np.all(np.isfinite(got))
+
+
 def test_profile_list_longer_than_expected(c2):
     """k_profile's one-item-per-workgroup launch is sized from the list lengths of recent
     launch groups; a list that turns out longer is finished by k_profile_rest.  Sparse
