@@ -60,6 +60,9 @@ constexpr int SEP_PITCH = (CONV_TX + 32) | 1;          // fused factorised beam,
 constexpr int DIRECT_PITCH = (CONV_TX + 32) | 1;       // fused direct taps, kpad <= 32: LDS tile pitch (room for the staging's column shift)
 constexpr int DIRECT_MIN_RANK = 6;           // beams needing this many terms or more get direct taps in the fused kernel
 constexpr int PREP_TILES = 1024;             // conv windows per axis pair k_prep can index (ntx + nty)
+// counter words of a launch group (zeroed by k_prep): [0] live windows, [1] window ticket, [2] k_plan's
+// items, [16..31] slamhip_group_counts, [32..47] phase stamps, [64 + 32 x] window ticket of XCD x
+constexpr int LIVECOUNT_WORDS = 320;
 constexpr int FLAG_MAX = 512;                // occupancy bytes one conv window may span
 
 // ---------------------------------------------------------------------------
@@ -171,7 +174,7 @@ __global__ void k_prep(FitK g, const double* __restrict__ params, int nw,
     // counters start every group at zero
     unsigned char* wf = winflag + (long long)w * winbytes;
     for (int i = threadIdx.x; i < winbytes; i += blockDim.x) wf[i] = 0;
-    if (w == 0 && threadIdx.x < 64) livecount[threadIdx.x] = 0;
+    if (w == 0) for (int i = threadIdx.x; i < LIVECOUNT_WORDS; i += blockDim.x) livecount[i] = 0;
   }
   const double* p = params + (long long)w * NP;
   WalkerK& o = wk[w];
@@ -1321,19 +1324,31 @@ __device__ __forceinline__ void lds_barrier() {
 // Row pass of one lane: C consecutive outputs res[c] += sum_u wx[u] row[c + u] over kpad
 // taps, the C-wide window of `row` rotating through registers (one LDS read per tap);
 // the taps come through the scalar cache (block-uniform address).  kpad is a multiple of RU.
+// LDS read that the compiler may not pair with its neighbour: a ds_read2_b64 costs 8 LDS cycles
+// for its 1 KiB, two ds_read_b64 cost 2 each (MI355X_MICROARCH.md, LDS table), and these kernels
+// wait on LDS round trips (k_conv_rows: 30.7 instead of 32.2 us/eval at C3)
+#ifndef CV_PAIRED_READS
+template <typename T> __device__ __forceinline__ T lds_rd(const T* p) {
+  typedef const volatile __attribute__((address_space(3))) T* lds_ptr;   // stays an LDS (ds_read) access
+  return *(lds_ptr)(p);
+}
+#else
+template <typename T> __device__ __forceinline__ T lds_rd(const T* p) { return *p; }
+#endif
+
 template <int C, int RU, typename T>
 __device__ __forceinline__ void row_taps(const T* row, const T* __restrict__ wx, int kpad, bool tail4, T* res) {
   static_assert(RU % C == 0, "the window rotation must close over one unrolled step");
   T win[C];
 #pragma unroll
-  for (int r = 0; r < C - 1; ++r) win[r] = row[r];
+  for (int r = 0; r < C - 1; ++r) win[r] = lds_rd(row + r);
   // tail4 (block-uniform): the last RU / 2 of the kpad padded taps are zero padding (K + 1 <=
   // kpad - 4, e.g. the folded 28 taps of a K = 27 beam in 32): the last step runs half its taps
   const int kfull = tail4 ? kpad - RU : kpad;
   for (int u0 = 0; u0 < kfull; u0 += RU) {
 #pragma unroll
     for (int qq = 0; qq < RU; ++qq) {
-      win[(qq + C - 1) % C] = row[u0 + qq + C - 1];
+      win[(qq + C - 1) % C] = lds_rd(row + u0 + qq + C - 1);
       const T wgt = wx[u0 + qq];
 #pragma unroll
       for (int r = 0; r < C; ++r) res[r] = fma(wgt, win[(r + qq) % C], res[r]);
@@ -1342,7 +1357,7 @@ __device__ __forceinline__ void row_taps(const T* row, const T* __restrict__ wx,
   if (tail4) {
 #pragma unroll
     for (int qq = 0; qq < RU / 2; ++qq) {
-      win[(qq + C - 1) % C] = row[kfull + qq + C - 1];
+      win[(qq + C - 1) % C] = lds_rd(row + kfull + qq + C - 1);
       const T wgt = wx[kfull + qq];
 #pragma unroll
       for (int r = 0; r < C; ++r) res[r] = fma(wgt, win[(r + qq) % C], res[r]);
@@ -1968,25 +1983,66 @@ k_conv_rows(FitK g, const T* __restrict__ iunif,
   constexpr int DW = sizeof(WinDesc) / 4;
   __shared__ __attribute__((aligned(16))) unsigned s_desc[2][DW];
   __shared__ int s_ticket;
-  int* queue = count + 1;
-  if ((int)blockIdx.x >= nlive) return;                     // whole workgroup
-  if (tid < DW) s_desc[0][tid] = reinterpret_cast<const unsigned*>(&list[blockIdx.x])[tid];
+  // XCD-LOCAL TICKETS.  Workgroups go to the eight XCDs round robin (blockIdx.x & 7), each XCD
+  // has its own L2, and neighbouring windows of the list (same plane, same walker) share halo
+  // tiles: XCD x walks the x-th eighth of the list with a ticket counter of its own (count[64 +
+  // 32 x]), so that a plane's windows meet in one L2; a workgroup whose XCD's eighth is used up
+  // goes on with the next XCD's.  Tickets come TICKET_B at a time (the counter is one address).
+  __shared__ int s_tend;
   constexpr int TICKET_B = 4;
-  if (tid == 0) s_ticket = (int)gridDim.x + atomicAdd(queue, TICKET_B);
+  const int nx8 = (nlive + 7) >> 3;
+  const int myx = blockIdx.x & 7, lb = blockIdx.x >> 3;
+  int vx = 0;                                               // thread 0: eighths given up so far
+  auto draw = [&](int& end) -> int {                        // thread 0: next batch [return, end)
+    while (vx < 8) {
+      const int x = (myx + vx) & 7;
+      const int lo = min(x * nx8, nlive), hi = min((x + 1) * nx8, nlive);
+      const int first = min(((int)gridDim.x + 7 - x) >> 3, hi - lo);   // taken by position
+      if (lo + first < hi) {
+        const int idx = lo + first + atomicAdd(count + 64 + 32 * x, TICKET_B);
+        if (idx < hi) { end = min(idx + TICKET_B, hi); return idx; }
+      }
+      ++vx;
+    }
+    end = nlive;
+    return nlive;
+  };
+  {
+    // first window by position in the own eighth, else by ticket; and the first batch
+    const int lo = min(myx * nx8, nlive), hi = min((myx + 1) * nx8, nlive);
+    if (tid == 0) {
+      int e0 = 0, e1 = 0;
+      int first = lo + lb < hi ? lo + lb : -1;
+      int t0 = draw(e0);
+      if (first < 0) {                                       // no window by position: the batch's first
+        first = t0;
+        t0 = t0 + 1 < e0 ? t0 + 1 : draw(e1);
+        if (!(first + 1 < e0)) e0 = e1;
+      }
+      s_desc[1][0] = (unsigned)first;
+      s_ticket = t0;
+      s_tend = e0;
+    }
+  }
   __syncthreads();
+  int it0 = (int)__builtin_amdgcn_readfirstlane(s_desc[1][0]);
+  if (it0 >= nlive) return;                                 // whole workgroup: nothing left anywhere
   int nxt = __builtin_amdgcn_readfirstlane(s_ticket);
-  int held = TICKET_B - 1;
+  int nend = __builtin_amdgcn_readfirstlane(s_tend);
+  __syncthreads();
+  if (tid < DW) s_desc[0][tid] = reinterpret_cast<const unsigned*>(&list[it0])[tid];
+  __syncthreads();
   int par = 0;
   // this lane in the staging (a quarter wave per row of a group, 16 bytes per lane) and in the
   // row pass (half waves take column blocks 0-3 / 4-7, eight row slots x four blocks each)
   const int srow = lane >> 4, scol = (lane & 15) * 2;
   const int pslot = (lane >> 2) & 7, pcb = ((lane >> 5) << 2) | (lane & 3);
-  for (int it = blockIdx.x; it < nlive; par ^= 1) {
+  for (int it = it0; it < nlive; par ^= 1) {
     unsigned nextw = 0;
     if (tid < DW && nxt < nlive)
       nextw = reinterpret_cast<const unsigned*>(&list[nxt])[tid];
-    int fut = nlive;
-    if (held == 0 && tid == 0 && nxt < nlive) fut = (int)gridDim.x + atomicAdd(queue, TICKET_B);
+    int fut = nlive, fend = nlive;
+    if (!(nxt + 1 < nend) && tid == 0 && nxt < nlive) fut = draw(fend);
     const unsigned hd = s_desc[par][lane & 15];
     const unsigned ocv = s_desc[par][44 + (lane & 1)];      // occupancy bitmap, first word (<= 52 tiles here)
     static_assert(offsetof(WinDesc, occ) == 44 * 4, "descriptor layout");
@@ -2153,7 +2209,7 @@ k_conv_rows(FitK g, const T* __restrict__ iunif,
           if (!(bits & ((1ull << (R + R / 2 - 1)) - 1ull))) continue;
           T win[R + R / 2 - 1];
 #pragma unroll
-          for (int r = 0; r < R + R / 2 - 1; ++r) win[r] = col[(u0 + r) * P];
+          for (int r = 0; r < R + R / 2 - 1; ++r) win[r] = lds_rd(col + (u0 + r) * P);
 #pragma unroll
           for (int qq = 0; qq < R / 2; ++qq) {
             const T wgt = wyr[u0 + qq];
@@ -2165,7 +2221,7 @@ k_conv_rows(FitK g, const T* __restrict__ iunif,
         if (!(bits & ((1ull << (2 * R - 1)) - 1ull))) continue;
         T win[2 * R - 1];
 #pragma unroll
-        for (int r = 0; r < 2 * R - 1; ++r) win[r] = col[(u0 + r) * P];
+        for (int r = 0; r < 2 * R - 1; ++r) win[r] = lds_rd(col + (u0 + r) * P);
 #pragma unroll
         for (int qq = 0; qq < R; ++qq) {
           const T wgt = wyr[u0 + qq];
@@ -2237,7 +2293,7 @@ k_conv_rows(FitK g, const T* __restrict__ iunif,
     ff = wave_sum_dpp(ff);
     if (lane == 0) { sg[wv] = gf; sf[wv] = ff; }
     if (tid < DW) s_desc[par ^ 1][tid] = nextw;
-    if (tid == 0) s_ticket = fut;
+    if (tid == 0) { s_ticket = fut; s_tend = fend; }
     lds_barrier();                                          // also: every wave is done with this window's rows
     if (tid == 0) {
       double av = 0.0, b2 = 0.0;
@@ -2248,8 +2304,8 @@ k_conv_rows(FitK g, const T* __restrict__ iunif,
       partial[3 * (long long)e + 2] = 1.0;
     }
     it = nxt;
-    if (held > 0) { nxt = nxt + 1; --held; }
-    else { nxt = __builtin_amdgcn_readfirstlane(s_ticket); held = TICKET_B - 1; }
+    if (nxt + 1 < nend) nxt = nxt + 1;                      // still inside the batch
+    else { nxt = __builtin_amdgcn_readfirstlane(s_ticket); nend = __builtin_amdgcn_readfirstlane(s_tend); }
   }
 }
 
@@ -3268,7 +3324,7 @@ size_t carve(const slamhip_ctx* c, size_t W, unsigned char* base, Scratch* s) {
   t.flags = take(W * k.nv * c->ftx * c->fty + 8);   // +8: k_compact reads rows 8 bytes at a time
   t.winflag = take(nwin);
   t.livelist = reinterpret_cast<WinDesc*>(take(nwin * sizeof(WinDesc)));
-  t.livecount = reinterpret_cast<int*>(take(64 * sizeof(int)));
+  t.livecount = reinterpret_cast<int*>(take(LIVECOUNT_WORDS * sizeof(int)));
   t.tile_ix = reinterpret_cast<int*>(take(W * c->fz_grid.x * 2 * sizeof(int)));
   t.tile_jy = reinterpret_cast<int*>(take(W * c->fz_grid.y * 2 * sizeof(int)));
   t.gxw = reinterpret_cast<double*>(take(W * (size_t)c->kpad * sizeof(double)));
