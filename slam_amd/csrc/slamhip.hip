@@ -2171,27 +2171,21 @@ k_conv_rows(FitK g, const T* __restrict__ iunif,
     // -- 3. row pass over the owned rows with emission, results in place (this wave's rows only)
     const T* __restrict__ wxr = fold_w ? gxw + (long long)wi * KP : gxp;
     const T* __restrict__ wyr = fold_w ? gyw + (long long)wi * KP : gyp;
-    T res[2][R];
-    int rrow[2];
+    // (a round's results go back in place at once: its lanes have all read their rows by then,
+    // and the next round reads other rows)
 #pragma unroll
     for (int rd = 0; rd < 2; ++rd) {
-#pragma unroll
-      for (int r = 0; r < R; ++r) res[rd][r] = 0;
-      rrow[rd] = -1;
       if (rd * 8 < nown) {                                  // wave-uniform
         const int slot = rd * 8 + pslot;
         if (slot < nown) {
-          rrow[rd] = s_rowlist[wv][slot];
-          row_taps<R, R>(tile + rrow[rd] * P + pcb * R, wxr, KP, tail4, res[rd]);
+          T res[R];
+#pragma unroll
+          for (int r = 0; r < R; ++r) res[r] = 0;
+          T* o = tile + s_rowlist[wv][slot] * P + pcb * R;
+          row_taps<R, R>(o, wxr, KP, tail4, res);
+#pragma unroll
+          for (int r = 0; r < R; ++r) o[r] = res[r];
         }
-      }
-    }
-#pragma unroll
-    for (int rd = 0; rd < 2; ++rd) {
-      if (rrow[rd] >= 0) {
-        T* o = tile + rrow[rd] * P + pcb * R;
-#pragma unroll
-        for (int r = 0; r < R; ++r) o[r] = res[rd][r];
       }
     }
     lds_barrier();                                          // every wave's rows hold the intermediate
