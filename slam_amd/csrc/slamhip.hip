@@ -1327,14 +1327,14 @@ __device__ __forceinline__ void lds_barrier() {
 // LDS read that the compiler may not pair with its neighbour: a ds_read2_b64 costs 8 LDS cycles
 // for its 1 KiB, two ds_read_b64 cost 2 each (MI355X_MICROARCH.md, LDS table), and these kernels
 // wait on LDS round trips (k_conv_rows: 30.7 instead of 32.2 us/eval at C3)
-#ifndef CV_PAIRED_READS
 template <typename T> __device__ __forceinline__ T lds_rd(const T* p) {
-  typedef const volatile __attribute__((address_space(3))) T* lds_ptr;   // stays an LDS (ds_read) access
-  return *(lds_ptr)(p);
+  if constexpr (sizeof(T) == 8) {
+    typedef const volatile __attribute__((address_space(3))) T* lds_ptr;   // stays an LDS (ds_read_b64) access
+    return *(lds_ptr)(p);
+  } else {
+    return *p;                         // floats: the paired / wide read is the cheaper one
+  }
 }
-#else
-template <typename T> __device__ __forceinline__ T lds_rd(const T* p) { return *p; }
-#endif
 
 template <int C, int RU, typename T>
 __device__ __forceinline__ void row_taps(const T* row, const T* __restrict__ wx, int kpad, bool tail4, T* res) {
@@ -1369,7 +1369,7 @@ __device__ __forceinline__ void row_taps(const T* row, const T* __restrict__ wx,
 // kpad); MULTI: the factorised beam may have several terms (false: exactly one, the column
 // pass's sums are then born after the row pass and cost it no registers)
 template <int TY, int MAXR, bool DIRECT, int PITCH = 0, typename T = double, bool MULTI = true>
-__global__ void __launch_bounds__(CV_NT, (sizeof(T) == 4 ? CV_MINW_F32 : 4))
+__global__ void __launch_bounds__(CV_NT, (sizeof(T) == 4 && TY == 64 && MAXR == 2 ? CV_MINW_F32 : 4))   // only the small float tile fits a CU three times
 k_conv_chi2(FitK g, const T* __restrict__ iunif,
             const int* __restrict__ cellx, const double* __restrict__ fracx,
             const int* __restrict__ celly, const double* __restrict__ fracy,
