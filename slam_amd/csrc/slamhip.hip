@@ -2093,7 +2093,7 @@ k_conv_rows(FitK g, const T* __restrict__ iunif,
       }
 #pragma unroll
       for (int fx = 0; fx < 4; ++fx) {
-        sv[gi][fx] = Real<T>::make2((T)0, (T)0);
+        sv[gi][fx] = Real<T>::make2((T)0, (T)0);         // (left uninitialised the compiler's code is 35 % slower)
         const bool present = rb < vrows && rb + 4 > 0 && Q >= 0 && fy >= 0 && fx < fnx &&
                              ((occ >> (fy * fnx + fx)) & 1ull);         // wave-uniform
         if (present) {
@@ -2115,8 +2115,8 @@ k_conv_rows(FitK g, const T* __restrict__ iunif,
     double dv[NRQ], t0q[NRQ];
     int i0q[NRQ];
 
-    // -- 1. zero the owned rows (all 95: the column pass reads the padded ones against zero taps),
-    //       list those with emission
+    // -- 1. zero the owned rows (all 95: the column pass reads the padded ones against zero taps;
+    //       rows without emission only where the column pass reads), list those with emission
 #pragma unroll
     for (int gi = 0; gi < NG; ++gi) {
       const int rb = 4 * (8 * gi + ((wv - gi) & 7)) - a;
@@ -2125,8 +2125,12 @@ k_conv_rows(FitK g, const T* __restrict__ iunif,
         const int r = rb + i;
         if (r < 0 || r >= ROWS) continue;                   // wave-uniform
         T* rowp = lds + r * P;
-        rowp[lane] = 0;
-        if (lane < P - 64) rowp[64 + lane] = 0;
+        if ((m16 >> (4 * gi + i)) & 1u) {                   // wave-uniform: the row pass reads all of it
+          rowp[lane] = 0;
+          if (lane < P - 64) rowp[64 + lane] = 0;
+        } else {
+          rowp[woff + lane] = 0;                            // only the column pass reads it: 64 columns
+        }
       }
     }
     const int nown = __popc(m16);
