@@ -1171,28 +1171,38 @@ k_compact(FitK g, const unsigned char* __restrict__ winflag, int total,
           const unsigned char* __restrict__ flags, int ftx, int fty,
           const int* __restrict__ tile_ix, const int* __restrict__ tile_jy,
           int wnx, int wny, int sx, int sy, int ty,
-          WinDesc* __restrict__ list, int* __restrict__ count, const WalkerK* __restrict__ wk) {
+          WinDesc* __restrict__ list, int* __restrict__ count, const WalkerK* __restrict__ wk,
+          int split) {
   const int e = blockIdx.x * 256 + threadIdx.x;
   // one counter update per wave (a single address takes ~1 atomic per clock):
   // lane 0 reserves the wave's slots, each live lane takes its rank among them
-  const bool live = e < total && winflag[e];
+  const bool live_any = e < total && winflag[e];
+  // split: windows of walkers whose regrid does not fold into the beam go to a second list that
+  // grows down from the end of `list` (count[3] entries: list[total - count[3] ..]), so that the
+  // windows of folded walkers can be run by a kernel instance without the regrid phase
+  const bool second = split && live_any && !wk[(e / (wnx * wny)) / g.nv].fold;
+  const bool live = live_any && !second;
   const unsigned long long lanes = __ballot(live);
   const int lane = threadIdx.x & 63;
+  const unsigned long long lanes2 = __ballot(second);
   // ONE counter update per workgroup: returning atomics on a single address are served
   // one after the other at memory (~12 ns each on this part: one per wave made them the
   // kernel's whole duration), so the four waves' counts meet in LDS first
-  __shared__ int s_cnt[4], s_base;
-  if (lane == 0) s_cnt[threadIdx.x >> 6] = __popcll(lanes);
+  __shared__ int s_cnt[4], s_base, s_cnt2[4], s_base2;
+  if (lane == 0) { s_cnt[threadIdx.x >> 6] = __popcll(lanes); s_cnt2[threadIdx.x >> 6] = __popcll(lanes2); }
   __syncthreads();
   if (threadIdx.x == 0) {
     const int tot = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
     s_base = tot ? atomicAdd(count, tot) : 0;
+    const int tot2 = s_cnt2[0] + s_cnt2[1] + s_cnt2[2] + s_cnt2[3];
+    s_base2 = tot2 ? atomicAdd(count + 3, tot2) : 0;
   }
   __syncthreads();
-  int slot = s_base;
-  for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) slot += s_cnt[w];
-  slot += __popcll(lanes & ((1ull << lane) - 1ull));
-  if (!live) return;
+  int slot = second ? s_base2 : s_base;
+  for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) slot += second ? s_cnt2[w] : s_cnt[w];
+  slot += __popcll((second ? lanes2 : lanes) & ((1ull << lane) - 1ull));
+  if (second) slot = total - 1 - slot;
+  if (!live_any) return;
   const int n = g.nneed;
   const int z = e / (wnx * wny), tl = e - z * (wnx * wny);
   const int tby = tl / wnx, tbx = tl - tby * wnx;
@@ -1955,7 +1965,7 @@ k_conv_chi2(FitK g, const T* __restrict__ iunif,
 // nothing any other wave touches, so none of this needs a barrier.  One barrier before the column
 // pass (which reads every wave's rows) and one after the sums are left.  Same arithmetic, same
 // order of operations per output as k_conv_chi2's fixed-pitch instance: chi2 is bitwise the same.
-template <typename T>
+template <typename T, bool REGRID>
 __global__ void __launch_bounds__(CV_NT, 4)
 k_conv_rows(FitK g, const T* __restrict__ iunif,
             const int* __restrict__ cellx, const double* __restrict__ fracx,
@@ -1963,7 +1973,11 @@ k_conv_rows(FitK g, const T* __restrict__ iunif,
             const WinDesc* __restrict__ list, int* __restrict__ count, int wnx, int wny,
             double* __restrict__ partial,
             const T* __restrict__ gxp, const T* __restrict__ gyp,
-            const T* __restrict__ gxw, const T* __restrict__ gyw, int tail4_arg) {
+            const T* __restrict__ gxw, const T* __restrict__ gyw, int tail4_arg, int rev_total) {
+  // REGRID = false: every window of `list` belongs to a walker whose regrid is folded into the
+  // beam taps (k_compact's first list): no conv tile, no bilinear phase, none of its state.
+  // REGRID = true: the general form, run on k_compact's second list (the last *count entries
+  // of the rev_total-entry array).
   extern __shared__ unsigned char lds_raw[];
   T* const lds = reinterpret_cast<T*>(lds_raw);
   using T2 = typename Real<T>::vec2;
@@ -1980,6 +1994,7 @@ k_conv_rows(FitK g, const T* __restrict__ iunif,
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nlive = *count;
+  if (REGRID) list += rev_total - nlive;
   constexpr int DW = sizeof(WinDesc) / 4;
   __shared__ __attribute__((aligned(16))) unsigned s_desc[2][DW];
   __shared__ int s_ticket;
@@ -2060,7 +2075,7 @@ k_conv_rows(FitK g, const T* __restrict__ iunif,
     const unsigned long long occ = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(ocv, 1) << 32) |
                                    (unsigned)__builtin_amdgcn_readlane(ocv, 0);
     const int fxw = head(2), fyw = head(4);
-    const bool fold_w = fxw < 0;                            // block-uniform
+    const bool fold_w = !REGRID || fxw < 0;                 // block-uniform
     const int fja = (fxw >> 8) & 255, fjb = (fxw >> 16) & 255;
     const int pixx = (fold_w && lane >= fja && lane < fjb) ? head(1) + ((fxw & 1) ? lane : -lane) : -1;
     const int woff = wx0 & 1;
@@ -2107,13 +2122,6 @@ k_conv_rows(FitK g, const T* __restrict__ iunif,
       }
     }
     const double* dat = g.data + (long long)k * g.ny * g.nx;
-    const int ixa = head(1), ixb = head(2);
-    const int jya = head(3), jyb = head(4);
-    const int ix = ixa + lane;
-    int i1 = -1;
-    double t1 = 0.0;
-    double dv[NRQ], t0q[NRQ];
-    int i0q[NRQ];
 
     // -- 1. zero the owned rows (all 95: the column pass reads the padded ones against zero taps;
     //       rows without emission only where the column pass reads), list those with emission
@@ -2236,8 +2244,15 @@ k_conv_rows(FitK g, const T* __restrict__ iunif,
         gf = fma(av, fdv[r], gf);
         ff = fma(av, av, ff);
       }
-    } else {
+    } else if constexpr (REGRID) {
       // conv tile + bilinear regrid, as k_conv_chi2
+      const int ixa = head(1), ixb = head(2);
+      const int jya = head(3), jyb = head(4);
+      const int ix = ixa + lane;
+      int i1 = -1;
+      double t1 = 0.0;
+      double dv[NRQ], t0q[NRQ];
+      int i0q[NRQ];
       if (ix < ixb) {
         i1 = cellx[(long long)wi * g.nx + ix] - x0;
         t1 = fracx[(long long)wi * g.nx + ix];
@@ -2498,11 +2513,12 @@ __device__ inline void count_add(unsigned long long* dst, unsigned long long v) 
 
 __global__ void __launch_bounds__(256)
 k_count_windows(const WinDesc* __restrict__ list, const int* __restrict__ count, int ty, int kpad,
-                int rb, unsigned long long* __restrict__ cnt) {
+                int rb, unsigned long long* __restrict__ cnt, int rev_total) {
   // rb: output rows per tap block -- CONV_R for the column pass of the factorised form; the
   // direct-tap form works on blocks of 2*CONV_R (64-row windows) or CONV_R output rows and
   // skips a block of CONV_R tap rows when the rb + CONV_R - 1 window rows under it are empty
   const int nlive = count[0];
+  if (rev_total) list += rev_total - nlive;                 // k_compact's second list
   unsigned long long nocc = 0, rows = 0, blocks = 0, live = 0;
   for (int e = blockIdx.x * 256 + threadIdx.x; e < nlive; e += gridDim.x * 256) {
     const WinDesc& d = list[e];
@@ -3108,6 +3124,7 @@ static __device__ __align__(256) unsigned char scratch[STATIC_SCRATCH_BYTES];
 // a second one out of the library's static device array.
 struct Scratch {
   int wgroup = 0;              // walkers per launch group
+  int wgroup_now = 0;          // walkers of the launch group in flight (sizes k_compact's list)
   WalkerK* wk = nullptr;
   double* params = nullptr;
   void* geom = nullptr;        // [walker][surface][sample] {vlos*sqrt(M), weight} as double2 or float2
@@ -3681,6 +3698,11 @@ const void* fused_instance(int variant, bool direct, bool fixed, bool multi = tr
                       : (const void*)k_conv_chi2<32, 2, true, 0, T>;
 }
 
+// the row-owning kernel's case: one-term beam of 25..32 padded taps, 64-row windows, double
+static bool rows_kernel(const slamhip_ctx* c, int fz_rank) {
+  return fz_rank == 1 && c->fz_variant == 0 && c->sep_fixed && !c->f32 && c->conv_mode != 4;
+}
+
 template <typename T>
 void launch_fused(slamhip_ctx* c, Scratch& S, int fz_rank, hipStream_t st, const T* gx, const T* gy,
                   const T* ft, const T* gxw, const T* gyw) {
@@ -3699,11 +3721,17 @@ void launch_fused(slamhip_ctx* c, Scratch& S, int fz_rank, hipStream_t st, const
   do { if (fz_rank == 1) SLAM_FUSED_M(TY_, MR_, false, 0, false); else SLAM_FUSED(TY_, MR_, false, 0); } while (0)
   switch (c->fz_variant) {
     case 0:
-      if (fz_rank == 1 && c->sep_fixed && sizeof(T) == 8 && c->conv_mode != 4)
-        hipLaunchKernelGGL((k_conv_rows<T>), gz, dim3(CV_NT), fz_lds, st, c->k, (const T*)S.iunif, S.cellx,
+      if (rows_kernel(c, fz_rank)) {
+        // folded walkers' windows, then (second list, usually empty: the workgroups leave at once)
+        // those that keep the conv tile + bilinear regrid
+        const int nwin = (int)(c->fz_grid.x * c->fz_grid.y * c->fz_grid.z) * S.wgroup_now;
+        hipLaunchKernelGGL((k_conv_rows<T, false>), gz, dim3(CV_NT), fz_lds, st, c->k, (const T*)S.iunif, S.cellx,
                            S.fracx, S.celly, S.fracy, S.livelist, S.livecount, (int)c->fz_grid.x,
-                           (int)c->fz_grid.y, S.partial, gx, gy, gxw, gyw, tail4);
-      else if (fz_rank == 1 && c->sep_fixed) SLAM_FUSED_M(64, 2, false, SEP_PITCH, false);
+                           (int)c->fz_grid.y, S.partial, gx, gy, gxw, gyw, tail4, 0);
+        hipLaunchKernelGGL((k_conv_rows<T, true>), gz, dim3(CV_NT), fz_lds, st, c->k, (const T*)S.iunif, S.cellx,
+                           S.fracx, S.celly, S.fracy, S.livelist, S.livecount + 3, (int)c->fz_grid.x,
+                           (int)c->fz_grid.y, S.partial, gx, gy, gxw, gyw, tail4, nwin);
+      } else if (fz_rank == 1 && c->sep_fixed) SLAM_FUSED_M(64, 2, false, SEP_PITCH, false);
       else if (fz_rank) SLAM_FUSED_SEP(64, 2);
       else if (c->direct_fixed) SLAM_FUSED(64, 2, true, DIRECT_PITCH);
       else SLAM_FUSED(64, 2, true, 0);
@@ -3732,7 +3760,8 @@ int run_group(slamhip_ctx* c, Scratch& S, const double* d_params, int nw, double
       hipLaunchKernelGGL(k_compact, dim3((nwin + 255) / 256), dim3(256), 0, st, c->k, S.winflag, nwin,
                          S.flags, c->ftx, c->fty, S.tile_ix, S.tile_jy,
                          (int)c->fz_grid.x, (int)c->fz_grid.y, c->fz_sx, c->fz_sy, c->fz_sy + 1,
-                         S.livelist, S.livecount, S.wk);
+                         S.livelist, S.livecount, S.wk, rows_kernel(c, fz_rank) ? 1 : 0);
+      S.wgroup_now = nw;
     }
     {
       Timed t_(c, KID_CONV, st);
@@ -4002,9 +4031,12 @@ int slamhip_create(const slamhip_desc* d, slamhip_ctx** out) {
     if (c->nrank >= 1 && c->sep_fixed) {
       const void* f2 = c->f32 ? fused_instance<float>(0, false, true, false) : fused_instance<double>(0, false, true, false);
       HIP_TRY(c, hipFuncSetAttribute(f2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->fz_lds));
-      if (!c->f32)
-        HIP_TRY(c, hipFuncSetAttribute((const void*)k_conv_rows<double>,
+      if (!c->f32) {
+        HIP_TRY(c, hipFuncSetAttribute((const void*)k_conv_rows<double, false>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->fz_lds));
+        HIP_TRY(c, hipFuncSetAttribute((const void*)k_conv_rows<double, true>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->fz_lds));
+      }
     }
     if (c->nrank >= 1) {
       HIP_TRY(c, hipFuncSetAttribute(fz, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->fz_lds));
@@ -4590,7 +4622,10 @@ int slamhip_group_counts(slamhip_ctx* c, int nw, int64_t* out) {
     const int fz_rank = (c->conv_mode == 2 && c->nrank >= 1) ? c->nrank : c->fz_rank;
     const int rb = fz_rank ? CONV_R : (ty == 64 ? 2 * CONV_R : CONV_R);
     hipLaunchKernelGGL(k_count_windows, dim3(512), dim3(256), 0, c->stream, S.livelist, S.livecount,
-                       ty, c->kpad, rb, cnt);
+                       ty, c->kpad, rb, cnt, 0);
+    if (rows_kernel(c, fz_rank))
+      hipLaunchKernelGGL(k_count_windows, dim3(512), dim3(256), 0, c->stream, S.livelist, S.livecount + 3,
+                         ty, c->kpad, rb, cnt, (int)(c->fz_grid.x * c->fz_grid.y * c->fz_grid.z) * nw);
   }
   hipLaunchKernelGGL(k_count_flags, dim3(1024), dim3(256), 0, c->stream, S.flags,
                      (long long)nw * k.nv * c->ftx * c->fty, S.gflag, (long long)nw * (k.nslot >> 6), cnt);
