@@ -1317,6 +1317,9 @@ constexpr int CV_NW = CV_NT / 64;            // waves
 #ifndef CV_NSB
 #define CV_NSB 7                             // staged tiles per wave held in registers
 #endif
+#ifndef CV_MINW_48
+#define CV_MINW_48 4
+#endif
 #ifndef CV_MINW_F32
 // waves per SIMD the float instances are compiled for: their tile is half the size, three
 // workgroups fit a CU's LDS, and 80 VGPRs (44 B of scratch in the hot instance) buy that
@@ -1379,7 +1382,7 @@ __device__ __forceinline__ void row_taps(const T* row, const T* __restrict__ wx,
 // kpad); MULTI: the factorised beam may have several terms (false: exactly one, the column
 // pass's sums are then born after the row pass and cost it no registers)
 template <int TY, int MAXR, bool DIRECT, int PITCH = 0, typename T = double, bool MULTI = true>
-__global__ void __launch_bounds__(CV_NT, (sizeof(T) == 4 && TY == 64 && MAXR == 2 ? CV_MINW_F32 : 4))   // only the small float tile fits a CU three times
+__global__ void __launch_bounds__(CV_NT, (sizeof(T) == 4 && TY == 64 && MAXR == 2 ? CV_MINW_F32 : TY == 48 ? CV_MINW_48 : 4))   // only the small float tile fits a CU three times
 k_conv_chi2(FitK g, const T* __restrict__ iunif,
             const int* __restrict__ cellx, const double* __restrict__ fracx,
             const int* __restrict__ celly, const double* __restrict__ fracy,
@@ -1965,8 +1968,8 @@ k_conv_chi2(FitK g, const T* __restrict__ iunif,
 // nothing any other wave touches, so none of this needs a barrier.  One barrier before the column
 // pass (which reads every wave's rows) and one after the sums are left.  Same arithmetic, same
 // order of operations per output as k_conv_chi2's fixed-pitch instance: chi2 is bitwise the same.
-template <typename T, bool REGRID>
-__global__ void __launch_bounds__(CV_NT, 4)
+template <typename T, bool REGRID, int TY = 64, int KP = 32>
+__global__ void __launch_bounds__(CV_NT, KP <= 32 ? 4 : 2)   // the 80-tap tile fills a CU's LDS once: 2 waves per SIMD
 k_conv_rows(FitK g, const T* __restrict__ iunif,
             const int* __restrict__ cellx, const double* __restrict__ fracx,
             const int* __restrict__ celly, const double* __restrict__ fracy,
@@ -1981,11 +1984,21 @@ k_conv_rows(FitK g, const T* __restrict__ iunif,
   extern __shared__ unsigned char lds_raw[];
   T* const lds = reinterpret_cast<T*>(lds_raw);
   using T2 = typename Real<T>::vec2;
-  constexpr int TY = 64, TX = CONV_TX, R = CONV_R, PC = TX + 1, KP = 32, P = SEP_PITCH;
-  constexpr int ROWS = TY + KP - 1;                         // 95 window rows incl. halo and tap padding
+  // TY x KP: 64 x 32 (K + 1 <= 32 taps, pitch 97, two workgroups per CU) or 48 x 80 (K <= 77:
+  // BASELINE config 4's beam; pitch 145, one workgroup per CU)
+  constexpr int TX = CONV_TX, R = CONV_R, PC = TX + 1, P = (TX + KP) | 1;
+  constexpr int RO = TY / CV_NW;                            // output rows per wave in the column pass
+  constexpr int ROWS = TY + KP - 1;                         // 95 / 127 window rows incl. halo and tap padding
   constexpr int NRQ = (TY - 1 + CV_NW - 1) / CV_NW;         // regrid rows per wave
-  constexpr int NG = 4;                                     // row groups a wave can own (25 groups, 8 waves)
+  constexpr int NG = 4;                                     // row groups a wave can own (25 / 32 groups, 8 waves)
+  constexpr int NFX = (TX + KP - 3 + PT_X - 1) / PT_X + 1;  // tile columns a window's rows can span (4 / 6)
+  constexpr bool OCC2 = ((ROWS + PT_Y - 1) / PT_Y + 1) * NFX > 64;   // occupancy bitmap needs a second word
+  static_assert(P == SEP_PITCH || KP != 32, "the pitch fz_tile_bytes gives");
   static_assert(P > TX + KP - 1 + 1, "room for the column shift");
+  static_assert(RO * CV_NW == TY && RO <= R, "column pass: every wave RO rows");
+  static_assert(NG * NFX <= 32 && ROWS <= 128, "masks");
+  // rows with image data (r < TY + K - 1) must lie in the 32 owned groups for any alignment a <= 3
+  // (slamhip_create checks K); rows beyond them up to ROWS are zeroed by the last wave
   __shared__ unsigned char s_rowlist[CV_NW][16];
   __shared__ double sg[CV_NW], sf[CV_NW];
   const bool tail4 = tail4_arg != 0;
@@ -2059,7 +2072,7 @@ k_conv_rows(FitK g, const T* __restrict__ iunif,
     int fut = nlive, fend = nlive;
     if (!(nxt + 1 < nend) && tid == 0 && nxt < nlive) fut = draw(fend);
     const unsigned hd = s_desc[par][lane & 15];
-    const unsigned ocv = s_desc[par][44 + (lane & 1)];      // occupancy bitmap, first word (<= 52 tiles here)
+    const unsigned ocv = s_desc[par][44 + (lane & 3)];      // occupancy bitmap (<= 52 tiles at 64 x 32, <= 102 at 48 x 80)
     static_assert(offsetof(WinDesc, occ) == 44 * 4, "descriptor layout");
     auto head = [&](int i) { return (int)__builtin_amdgcn_readlane(hd, i); };
     const int e = head(0);
@@ -2074,6 +2087,14 @@ k_conv_rows(FitK g, const T* __restrict__ iunif,
     const int fnx = min(wx0 + vcols - 1, n - 1) / PT_X - ftx0 + 1;
     const unsigned long long occ = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(ocv, 1) << 32) |
                                    (unsigned)__builtin_amdgcn_readlane(ocv, 0);
+    unsigned long long occ_hi = 0ull;
+    if constexpr (OCC2)
+      occ_hi = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(ocv, 3) << 32) |
+               (unsigned)__builtin_amdgcn_readlane(ocv, 2);
+    auto occupied = [&](int idx) -> bool {                  // wave-uniform
+      if constexpr (OCC2) return ((idx < 64 ? occ >> idx : occ_hi >> (idx - 64)) & 1ull) != 0ull;
+      else return ((occ >> idx) & 1ull) != 0ull;
+    };
     const int fxw = head(2), fyw = head(4);
     const bool fold_w = !REGRID || fxw < 0;                 // block-uniform
     const int fja = (fxw >> 8) & 255, fjb = (fxw >> 16) & 255;
@@ -2088,8 +2109,8 @@ k_conv_rows(FitK g, const T* __restrict__ iunif,
     // -- 0. this wave's row groups: group q holds window rows 4q - a .. 4q - a + 3, image rows
     //       4 (mq + q) ..; its tiles are the half `Q & 1` of tile row Q >> 1
     const int a = wy0 & 3, mq = wy0 >> 2;                   // floor semantics for negative wy0 too
-    T2 sv[NG][4];
-    unsigned sok = 0u;                                      // bit 4 gi + fx: this lane holds a pair there
+    T2 sv[NG][NFX];
+    unsigned sok = 0u;                                      // bit NFX gi + fx: this lane holds a pair there
     unsigned m16 = 0u;                                      // bit 4 gi + i: that owned row holds emission
 #pragma unroll
     for (int gi = 0; gi < NG; ++gi) {
@@ -2107,16 +2128,16 @@ k_conv_rows(FitK g, const T* __restrict__ iunif,
         if (rb < ROWS) m16 |= (unsigned)(bits & 15ull) << (4 * gi);
       }
 #pragma unroll
-      for (int fx = 0; fx < 4; ++fx) {
+      for (int fx = 0; fx < NFX; ++fx) {
         sv[gi][fx] = Real<T>::make2((T)0, (T)0);         // (left uninitialised the compiler's code is 35 % slower)
         const bool present = rb < vrows && rb + 4 > 0 && Q >= 0 && fy >= 0 && fx < fnx &&
-                             ((occ >> (fy * fnx + fx)) & 1ull);         // wave-uniform
+                             occupied(fy * fnx + fx);                   // wave-uniform
         if (present) {
           const int irow = 4 * Q + srow, icol = (ftx0 + fx) * PT_X + scol;
           const int r = rb + srow, cc = icol - wx0;
           if (r >= 0 && r < vrows && irow < n && icol < n && cc >= -woff && cc < vcols) {
             sv[gi][fx] = *reinterpret_cast<const T2*>(src + (long long)irow * n + icol);
-            sok |= 1u << (4 * gi + fx);
+            sok |= 1u << (NFX * gi + fx);
           }
         }
       }
@@ -2134,12 +2155,17 @@ k_conv_rows(FitK g, const T* __restrict__ iunif,
         if (r < 0 || r >= ROWS) continue;                   // wave-uniform
         T* rowp = lds + r * P;
         if ((m16 >> (4 * gi + i)) & 1u) {                   // wave-uniform: the row pass reads all of it
-          rowp[lane] = 0;
-          if (lane < P - 64) rowp[64 + lane] = 0;
+#pragma unroll
+          for (int c0 = 0; c0 < P; c0 += 64)
+            if (c0 + 64 <= P || lane < P - c0) rowp[c0 + lane] = 0;
         } else {
           rowp[woff + lane] = 0;                            // only the column pass reads it: 64 columns
         }
       }
+    }
+    if constexpr (4 * 8 * NG - 3 < ROWS) {                  // rows behind the last group (never lit)
+      if (wv == CV_NW - 1)
+        for (int r = 4 * 8 * NG - a; r < ROWS; ++r) lds[r * P + woff + lane] = 0;
     }
     const int nown = __popc(m16);
     if (lane < 16 && ((m16 >> lane) & 1u)) {
@@ -2153,27 +2179,27 @@ k_conv_rows(FitK g, const T* __restrict__ iunif,
     for (int gi = 0; gi < NG; ++gi) {
       const int rb = 4 * (8 * gi + ((wv - gi) & 7)) - a;
 #pragma unroll
-      for (int fx = 0; fx < 4; ++fx) {
-        if ((sok >> (4 * gi + fx)) & 1u) {
+      for (int fx = 0; fx < NFX; ++fx) {
+        if ((sok >> (NFX * gi + fx)) & 1u) {
           T* o = tile + (rb + srow) * P + ((ftx0 + fx) * PT_X + scol - wx0);
           o[0] = sv[gi][fx].x;
           o[1] = sv[gi][fx].y;
         }
       }
     }
-    double fdv[R];
+    double fdv[RO];
     unsigned fvalid = 0u;
 #pragma unroll
-    for (int r = 0; r < R; ++r) fdv[r] = 0.0;
+    for (int r = 0; r < RO; ++r) fdv[r] = 0.0;
     if (fold_w) {
       const int ya = (fyw >> 8) & 255, yb = (fyw >> 16) & 255;
-      const int rlo = max(ya - wv * R, 0), rhi = min(yb - wv * R, R);
+      const int rlo = max(ya - wv * RO, 0), rhi = min(yb - wv * RO, RO);
       if (rhi > rlo) fvalid = ((1u << rhi) - 1u) & ~((1u << rlo) - 1u);
       const long long step = (fyw & 1) ? (long long)g.nx : -(long long)g.nx;
-      const double* rowp = dat + (long long)(head(3) + ((fyw & 1) ? wv * R : -(wv * R))) * g.nx;
+      const double* rowp = dat + (long long)(head(3) + ((fyw & 1) ? wv * RO : -(wv * RO))) * g.nx;
       if (pixx >= 0) {
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
+        for (int r = 0; r < RO; ++r) {
           if ((fvalid >> r) & 1u) fdv[r] = rowp[pixx];      // wave-uniform test
           rowp += step;
         }
@@ -2202,44 +2228,55 @@ k_conv_rows(FitK g, const T* __restrict__ iunif,
     }
     lds_barrier();                                          // every wave's rows hold the intermediate
 
-    // -- 4. column pass: out[y][x] = sum_u gyf[u] tmp[y + u][x]  (lanes <-> x, waves <-> 8 rows)
-    T acc[R];
+    // -- 4. column pass: out[y][x] = sum_u gyf[u] tmp[y + u][x]  (lanes <-> x, waves <-> RO rows,
+    //       tap blocks of R)
+    T acc[RO];
 #pragma unroll
-    for (int r = 0; r < R; ++r) acc[r] = 0;
+    for (int r = 0; r < RO; ++r) acc[r] = 0;
     {
-      const T* col = tile + (wv * R) * P + lane;
-      const unsigned long long mcol = wv ? (m0 >> (wv * R)) | (m1 << (64 - wv * R)) : m0;
+      const T* col = tile + (wv * RO) * P + lane;
+      // the row masks from this wave's first row on; 64 bits reach every tap block of the 32-tap
+      // tile, the 80-tap one slides a 128-bit mask down one tap block per trip
+      unsigned long long mcol = wv ? (m0 >> (wv * RO)) | (m1 << (64 - wv * RO)) : m0;
+      unsigned long long mcol_hi = m1 >> (wv * RO);
       for (int u0 = 0; u0 < KP; u0 += R) {
-        const unsigned long long bits = mcol >> u0;
+        unsigned long long bits;
+        if constexpr (KP + RO - 1 <= 64) {
+          bits = mcol >> u0;
+        } else {
+          bits = mcol;
+          mcol = (mcol >> R) | (mcol_hi << (64 - R));
+          mcol_hi >>= R;
+        }
         if (tail4 && u0 == KP - R) {
-          if (!(bits & ((1ull << (R + R / 2 - 1)) - 1ull))) continue;
-          T win[R + R / 2 - 1];
+          if (!(bits & ((1ull << (RO + R / 2 - 1)) - 1ull))) continue;
+          T win[RO + R / 2 - 1];
 #pragma unroll
-          for (int r = 0; r < R + R / 2 - 1; ++r) win[r] = lds_rd(col + (u0 + r) * P);
+          for (int r = 0; r < RO + R / 2 - 1; ++r) win[r] = lds_rd(col + (u0 + r) * P);
 #pragma unroll
           for (int qq = 0; qq < R / 2; ++qq) {
             const T wgt = wyr[u0 + qq];
 #pragma unroll
-            for (int r = 0; r < R; ++r) acc[r] = fma(wgt, win[r + qq], acc[r]);
+            for (int r = 0; r < RO; ++r) acc[r] = fma(wgt, win[r + qq], acc[r]);
           }
           continue;
         }
-        if (!(bits & ((1ull << (2 * R - 1)) - 1ull))) continue;
-        T win[2 * R - 1];
+        if (!(bits & ((1ull << (RO + R - 1)) - 1ull))) continue;
+        T win[RO + R - 1];
 #pragma unroll
-        for (int r = 0; r < 2 * R - 1; ++r) win[r] = lds_rd(col + (u0 + r) * P);
+        for (int r = 0; r < RO + R - 1; ++r) win[r] = lds_rd(col + (u0 + r) * P);
 #pragma unroll
         for (int qq = 0; qq < R; ++qq) {
           const T wgt = wyr[u0 + qq];
 #pragma unroll
-          for (int r = 0; r < R; ++r) acc[r] = fma(wgt, win[r + qq], acc[r]);
+          for (int r = 0; r < RO; ++r) acc[r] = fma(wgt, win[r + qq], acc[r]);
         }
       }
     }
     double gf = 0.0, ff = 0.0;
     if (fold_w) {
 #pragma unroll
-      for (int r = 0; r < R; ++r) {
+      for (int r = 0; r < RO; ++r) {
         const double av = (pixx >= 0 && ((fvalid >> r) & 1u)) ? (double)acc[r] : 0.0;
         gf = fma(av, fdv[r], gf);
         ff = fma(av, av, ff);
@@ -2268,7 +2305,7 @@ k_conv_rows(FitK g, const T* __restrict__ iunif,
       const bool xown = i1 >= 0 && i1 < TX - 1;
       lds_barrier();                                        // column pass done reading LDS
 #pragma unroll
-      for (int r = 0; r < R; ++r) lds[(wv * R + r) * PC + lane] = acc[r];
+      for (int r = 0; r < RO; ++r) lds[(wv * RO + r) * PC + lane] = acc[r];
       lds_barrier();
 #pragma unroll
       for (int q = 0; q < NRQ; ++q) {
@@ -3698,9 +3735,13 @@ const void* fused_instance(int variant, bool direct, bool fixed, bool multi = tr
                       : (const void*)k_conv_chi2<32, 2, true, 0, T>;
 }
 
-// the row-owning kernel's case: one-term beam of 25..32 padded taps, 64-row windows, double
+// the row-owning kernel's cases, both one-term beams in double: 25..32 padded taps on 64-row
+// windows, or 80 padded taps of a K <= 77 beam on 48-row windows (its 32 row groups hold every row
+// with image data)
 static bool rows_kernel(const slamhip_ctx* c, int fz_rank) {
-  return fz_rank == 1 && c->fz_variant == 0 && c->sep_fixed && !c->f32 && c->conv_mode != 4;
+  if (fz_rank != 1 || c->f32 || c->conv_mode == 4) return false;
+  return (c->fz_variant == 0 && c->sep_fixed) ||
+         (c->fz_variant == 3 && c->kpad == 80 && c->k.kbeam <= 77);
 }
 
 template <typename T>
@@ -3737,7 +3778,19 @@ void launch_fused(slamhip_ctx* c, Scratch& S, int fz_rank, hipStream_t st, const
       else SLAM_FUSED(64, 2, true, 0);
       break;
     case 1: if (fz_rank) SLAM_FUSED_SEP(64, 3); else SLAM_FUSED(64, 3, true, 0); break;
-    case 3: SLAM_FUSED_M(48, 2, false, 0, false); break;      // one-term beams only (slamhip_create)
+    case 3:                                                   // one-term beams only (slamhip_create)
+      if (rows_kernel(c, fz_rank)) {
+        if constexpr (sizeof(T) == 8) {
+          const int nwin = (int)(c->fz_grid.x * c->fz_grid.y * c->fz_grid.z) * S.wgroup_now;
+          hipLaunchKernelGGL((k_conv_rows<T, false, 48, 80>), gz, dim3(CV_NT), fz_lds, st, c->k, (const T*)S.iunif,
+                             S.cellx, S.fracx, S.celly, S.fracy, S.livelist, S.livecount, (int)c->fz_grid.x,
+                             (int)c->fz_grid.y, S.partial, gx, gy, gxw, gyw, tail4, 0);
+          hipLaunchKernelGGL((k_conv_rows<T, true, 48, 80>), gz, dim3(CV_NT), fz_lds, st, c->k, (const T*)S.iunif,
+                             S.cellx, S.fracx, S.celly, S.fracy, S.livelist, S.livecount + 3, (int)c->fz_grid.x,
+                             (int)c->fz_grid.y, S.partial, gx, gy, gxw, gyw, tail4, nwin);
+        }
+      } else SLAM_FUSED_M(48, 2, false, 0, false);
+      break;
     default: if (fz_rank) SLAM_FUSED_SEP(32, 2); else SLAM_FUSED(32, 2, true, 0); break;
   }
 #undef SLAM_FUSED_SEP
@@ -4037,6 +4090,12 @@ int slamhip_create(const slamhip_desc* d, slamhip_ctx** out) {
         HIP_TRY(c, hipFuncSetAttribute((const void*)k_conv_rows<double, true>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->fz_lds));
       }
+    }
+    if (c->nrank == 1 && c->fz_variant == 3 && !c->f32) {
+      HIP_TRY(c, hipFuncSetAttribute((const void*)k_conv_rows<double, false, 48, 80>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->fz_lds));
+      HIP_TRY(c, hipFuncSetAttribute((const void*)k_conv_rows<double, true, 48, 80>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->fz_lds));
     }
     if (c->nrank >= 1) {
       HIP_TRY(c, hipFuncSetAttribute(fz, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->fz_lds));

@@ -417,6 +417,35 @@ def test_row_owning_kernel_equals_phase_kernel(c2):
     assert np.all(np.isfinite(got))
 
 
+def test_row_owning_kernel_80_taps_equals_phase_kernel():
+    """The same for BASELINE config 4's beam (K = 77: 80 padded taps, 48-row windows, one
+    workgroup per CU): k_conv_rows<48, 80> against k_conv_chi2's 48-row instance (mode 4) and
+    against the conv tile + bilinear regrid (mode 3), windows at every image edge, shifted
+    walkers (second window list) among the folded ones.  The waves split the output rows
+    differently (8 x 6 instead of 6 x 8), so the window sums add in another order: 1e-12."""
+    from slam_amd import synth
+    fit = synth.make_fit('big', N=192, NV=12, beam_px=(24, 18))
+    eng = fit.engine
+    ws = eng.window_shape()
+    assert (ws['rows'], ws['kpad']) == (48, 80)
+    P = np.concatenate([synth.walkers(20), synth.walkers(6, workload='dense_disk')])
+    P[:, 0] *= 0.3                              # keep the emission inside the 12 channels
+    P[3, 8:10] = (3.3, -7.1)
+    P[4, 8:10] = (-55.0, 61.0)
+    got = eng.chi2_stats(P)
+    eng.set_conv_mode(4)
+    old = eng.chi2_stats(P)
+    eng.set_conv_mode(3)
+    unf = eng.chi2_stats(P)
+    eng.set_conv_mode(0)
+    assert np.all(np.isfinite(got['chi2'])) and np.all(got['ff'] > 0)
+    for key in ('gf', 'ff', 'chi2'):
+        np.testing.assert_allclose(got[key], old[key], rtol=1e-12, err_msg=key)
+        np.testing.assert_allclose(unf[key], got[key], rtol=1e-11, err_msg=key)
+    assert np.array_equal(eng.chi2_stats(P)['chi2'], got['chi2'])
+    fit.close()
+
+
 def test_profile_list_longer_than_expected(c2):
     """k_profile's one-item-per-workgroup launch is sized from the list lengths of recent
     launch groups; a list that turns out longer is finished by k_profile_rest.  Sparse
