@@ -1956,6 +1956,28 @@ k_conv_chi2(FitK g, const T* __restrict__ iunif,
 #undef STAMP
 }
 
+// One round of k_conv_rows' row pass: `cnt` (<= 64 / (64 / C) ...) listed rows, 64 / C lanes per row,
+// C outputs per lane.  Groups of four adjacent lanes take four adjacent column blocks of a row, the
+// next four lanes the next row.
+template <int C, typename T>
+__device__ __forceinline__ void row_round(T* tile, const unsigned char* rowlist, int cnt, int lane,
+                                          const T* __restrict__ wx, int kp, bool tail4, int P) {
+  constexpr int SLOTS = C;                                  // rows per round: 64 lanes / (64 / C lanes per row)
+  constexpr int LG = C == 8 ? 3 : C == 4 ? 2 : 1;
+  static_assert(C == 8 || C == 4 || C == 2, "lane layout");
+  const int slot = (lane >> 2) & (SLOTS - 1);
+  const int cb = ((lane >> (2 + LG)) << 2) | (lane & 3);
+  if (slot < cnt) {
+    T res[C];
+#pragma unroll
+    for (int r = 0; r < C; ++r) res[r] = 0;
+    T* o = tile + rowlist[slot] * P + cb * C;
+    row_taps<C, CONV_R>(o, wx, kp, tail4, res);
+#pragma unroll
+    for (int r = 0; r < C; ++r) o[r] = res[r];
+  }
+}
+
 // k_conv_rows: k_conv_chi2's one-term, K + 1 <= 32 taps, 64-row-window case with the window's
 // ROWS OWNED BY WAVES.  k_conv_chi2 walks a window in phases that every wave must finish before
 // any wave may go on (zero the tile | stage the tiles | row pass | write the intermediate | column
@@ -2061,10 +2083,18 @@ k_conv_rows(FitK g, const T* __restrict__ iunif,
   if (tid < DW) s_desc[0][tid] = reinterpret_cast<const unsigned*>(&list[it0])[tid];
   __syncthreads();
   int par = 0;
+  // (diagnostic build: cycles of wave 0 per phase, as in k_conv_chi2; the first list's launch only)
+#ifdef SLAMHIP_PHASE_STAMPS
+  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev;
+#define STAMP_NOW(t_) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define STAMP(p_) do { unsigned long long t_; STAMP_NOW(t_); tacc[p_] += t_ - tprev; tprev = t_; } while (0)
+  STAMP_NOW(tprev);
+#else
+#define STAMP(p_) do { } while (0)
+#endif
   // this lane in the staging (a quarter wave per row of a group, 16 bytes per lane) and in the
   // row pass (half waves take column blocks 0-3 / 4-7, eight row slots x four blocks each)
   const int srow = lane >> 4, scol = (lane & 15) * 2;
-  const int pslot = (lane >> 2) & 7, pcb = ((lane >> 5) << 2) | (lane & 3);
   for (int it = it0; it < nlive; par ^= 1) {
     unsigned nextw = 0;
     if (tid < DW && nxt < nlive)
@@ -2091,10 +2121,6 @@ k_conv_rows(FitK g, const T* __restrict__ iunif,
     if constexpr (OCC2)
       occ_hi = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(ocv, 3) << 32) |
                (unsigned)__builtin_amdgcn_readlane(ocv, 2);
-    auto occupied = [&](int idx) -> bool {                  // wave-uniform
-      if constexpr (OCC2) return ((idx < 64 ? occ >> idx : occ_hi >> (idx - 64)) & 1ull) != 0ull;
-      else return ((occ >> idx) & 1ull) != 0ull;
-    };
     const int fxw = head(2), fyw = head(4);
     const bool fold_w = !REGRID || fxw < 0;                 // block-uniform
     const int fja = (fxw >> 8) & 255, fjb = (fxw >> 16) & 255;
@@ -2109,8 +2135,18 @@ k_conv_rows(FitK g, const T* __restrict__ iunif,
     // -- 0. this wave's row groups: group q holds window rows 4q - a .. 4q - a + 3, image rows
     //       4 (mq + q) ..; its tiles are the half `Q & 1` of tile row Q >> 1
     const int a = wy0 & 3, mq = wy0 >> 2;                   // floor semantics for negative wy0 too
+    // (the tests are split into what depends on the tile column -- per lane, once per window --,
+    // on the group -- wave-uniform -- and on the lane's row: the 16 / 24 slots then cost a scalar
+    // bit test each; written slot by slot the set-up was a fifth of the window's time)
+    unsigned colm = 0u;                                     // bit fx: this lane's pair of tile column fx lies in the window
+#pragma unroll
+    for (int fx = 0; fx < NFX; ++fx) {
+      const int icol = (ftx0 + fx) * PT_X + scol, cc = icol - wx0;
+      if (fx < fnx && icol < n && cc >= -woff && cc < vcols) colm |= 1u << fx;
+    }
     T2 sv[NG][NFX];
     unsigned sok = 0u;                                      // bit NFX gi + fx: this lane holds a pair there
+    unsigned uocc = 0u;                                     // wave-uniform, same bits: the tile half holds emission
     unsigned m16 = 0u;                                      // bit 4 gi + i: that owned row holds emission
 #pragma unroll
     for (int gi = 0; gi < NG; ++gi) {
@@ -2127,22 +2163,30 @@ k_conv_rows(FitK g, const T* __restrict__ iunif,
         if (rb < 0) bits <<= -rb;
         if (rb < ROWS) m16 |= (unsigned)(bits & 15ull) << (4 * gi);
       }
+      unsigned rowocc = 0u;                                 // wave-uniform: the group's tile halves with emission
+      if (rb < vrows && rb + 4 > 0 && Q >= 0 && fy >= 0) {
+        const int sh = fy * fnx;
+        unsigned long long w;
+        if constexpr (OCC2) w = sh < 64 ? (occ >> sh) | (sh ? occ_hi << (64 - sh) : 0ull) : occ_hi >> (sh - 64);
+        else w = occ >> sh;
+        rowocc = (unsigned)w & ((1u << fnx) - 1u);
+      }
+      uocc |= rowocc << (NFX * gi);
+      const int r = rb + srow, irow = 4 * Q + srow;
+      const unsigned lanem = (r >= 0 && r < vrows && irow < n) ? (colm & rowocc) : 0u;
+      sok |= lanem << (NFX * gi);
+      const T* rp = src + ((long long)irow * n + (ftx0 * PT_X + scol));
 #pragma unroll
-      for (int fx = 0; fx < NFX; ++fx) {
+      for (int fx = 0; fx < NFX; ++fx)
         sv[gi][fx] = Real<T>::make2((T)0, (T)0);         // (left uninitialised the compiler's code is 35 % slower)
-        const bool present = rb < vrows && rb + 4 > 0 && Q >= 0 && fy >= 0 && fx < fnx &&
-                             occupied(fy * fnx + fx);                   // wave-uniform
-        if (present) {
-          const int irow = 4 * Q + srow, icol = (ftx0 + fx) * PT_X + scol;
-          const int r = rb + srow, cc = icol - wx0;
-          if (r >= 0 && r < vrows && irow < n && icol < n && cc >= -woff && cc < vcols) {
-            sv[gi][fx] = *reinterpret_cast<const T2*>(src + (long long)irow * n + icol);
-            sok |= 1u << (NFX * gi + fx);
-          }
-        }
+      if (rowocc) {                                         // wave-uniform: groups without emission cost one branch
+#pragma unroll
+        for (int fx = 0; fx < NFX; ++fx)
+          if ((lanem >> fx) & 1u) sv[gi][fx] = *reinterpret_cast<const T2*>(rp + fx * PT_X);
       }
     }
     const double* dat = g.data + (long long)k * g.ny * g.nx;
+    STAMP(0);
 
     // -- 1. zero the owned rows (all 95: the column pass reads the padded ones against zero taps;
     //       rows without emission only where the column pass reads), list those with emission
@@ -2174,16 +2218,19 @@ k_conv_rows(FitK g, const T* __restrict__ iunif,
           (unsigned char)(4 * (8 * gi + ((wv - gi) & 7)) - a + (lane & 3));
     }
 
+    STAMP(1);
     // -- 2. the tile halves on the owned rows
 #pragma unroll
     for (int gi = 0; gi < NG; ++gi) {
       const int rb = 4 * (8 * gi + ((wv - gi) & 7)) - a;
+      T* ob = tile + (rb + srow) * P + (ftx0 * PT_X + scol - wx0);
+      if ((uocc >> (NFX * gi)) & ((1u << NFX) - 1u)) {      // wave-uniform
 #pragma unroll
-      for (int fx = 0; fx < NFX; ++fx) {
-        if ((sok >> (NFX * gi + fx)) & 1u) {
-          T* o = tile + (rb + srow) * P + ((ftx0 + fx) * PT_X + scol - wx0);
-          o[0] = sv[gi][fx].x;
-          o[1] = sv[gi][fx].y;
+        for (int fx = 0; fx < NFX; ++fx) {
+          if ((sok >> (NFX * gi + fx)) & 1u) {
+            ob[fx * PT_X] = sv[gi][fx].x;
+            ob[fx * PT_X + 1] = sv[gi][fx].y;
+          }
         }
       }
     }
@@ -2206,27 +2253,24 @@ k_conv_rows(FitK g, const T* __restrict__ iunif,
       }
     }
 
+    STAMP(2);
     // -- 3. row pass over the owned rows with emission, results in place (this wave's rows only)
     const T* __restrict__ wxr = fold_w ? gxw + (long long)wi * KP : gxp;
     const T* __restrict__ wyr = fold_w ? gyw + (long long)wi * KP : gyp;
-    // (a round's results go back in place at once: its lanes have all read their rows by then,
-    // and the next round reads other rows)
-#pragma unroll
-    for (int rd = 0; rd < 2; ++rd) {
-      if (rd * 8 < nown) {                                  // wave-uniform
-        const int slot = rd * 8 + pslot;
-        if (slot < nown) {
-          T res[R];
-#pragma unroll
-          for (int r = 0; r < R; ++r) res[r] = 0;
-          T* o = tile + s_rowlist[wv][slot] * P + pcb * R;
-          row_taps<R, R>(o, wxr, KP, tail4, res);
-#pragma unroll
-          for (int r = 0; r < R; ++r) o[r] = res[r];
-        }
-      }
+    // A round takes up to 8 listed rows (8 lanes per row, R outputs per lane) and writes its results
+    // back in place at once: its lanes have all read their rows by then, and the next round reads
+    // other rows.  A remainder of 3-4 rows runs 16 lanes per row with R / 2 outputs each, one of 1-2
+    // rows 32 lanes per row: half / a quarter of a round's multiply-adds instead of idle lanes (the
+    // waves meet at the barrier below: the one with 9-12 rows sets the pace).
+    for (int done = 0; done < nown;) {                      // wave-uniform
+      const int rem = nown - done;
+      if (rem > R / 2) { row_round<R>(tile, s_rowlist[wv] + done, min(rem, 8), lane, wxr, KP, tail4, P); done += 8; }
+      else if (rem > R / 4) { row_round<R / 2>(tile, s_rowlist[wv] + done, rem, lane, wxr, KP, tail4, P); done += 4; }
+      else { row_round<R / 4>(tile, s_rowlist[wv] + done, rem, lane, wxr, KP, tail4, P); done += 2; }
     }
+    STAMP(3);
     lds_barrier();                                          // every wave's rows hold the intermediate
+    STAMP(4);
 
     // -- 4. column pass: out[y][x] = sum_u gyf[u] tmp[y + u][x]  (lanes <-> x, waves <-> RO rows,
     //       tap blocks of R)
@@ -2273,6 +2317,7 @@ k_conv_rows(FitK g, const T* __restrict__ iunif,
         }
       }
     }
+    STAMP(5);
     double gf = 0.0, ff = 0.0;
     if (fold_w) {
 #pragma unroll
@@ -2344,7 +2389,9 @@ k_conv_rows(FitK g, const T* __restrict__ iunif,
     if (lane == 0) { sg[wv] = gf; sf[wv] = ff; }
     if (tid < DW) s_desc[par ^ 1][tid] = nextw;
     if (tid == 0) { s_ticket = fut; s_tend = fend; }
+    STAMP(6);
     lds_barrier();                                          // also: every wave is done with this window's rows
+    STAMP(7);
     if (tid == 0) {
       double av = 0.0, b2 = 0.0;
 #pragma unroll
@@ -2357,6 +2404,13 @@ k_conv_rows(FitK g, const T* __restrict__ iunif,
     if (nxt + 1 < nend) nxt = nxt + 1;                      // still inside the batch
     else { nxt = __builtin_amdgcn_readfirstlane(s_ticket); nend = __builtin_amdgcn_readfirstlane(s_tend); }
   }
+#ifdef SLAMHIP_PHASE_STAMPS
+  if (!REGRID && tid == 0) {
+    unsigned long long* dbg = reinterpret_cast<unsigned long long*>(count + 32);
+    for (int p_ = 0; p_ < 8; ++p_) atomicAdd(&dbg[p_], tacc[p_]);
+  }
+#endif
+#undef STAMP
 }
 
 // k_conv_2d: general (rotated) beam, direct K x K taps on an LDS tile.
