@@ -1991,7 +1991,7 @@ __device__ __forceinline__ void row_round(T* tile, const unsigned char* rowlist,
 // pass (which reads every wave's rows) and one after the sums are left.  Same arithmetic, same
 // order of operations per output as k_conv_chi2's fixed-pitch instance: chi2 is bitwise the same.
 template <typename T, bool REGRID, int TY = 64, int KP = 32>
-__global__ void __launch_bounds__(CV_NT, KP <= 32 ? 4 : 2)   // the 80-tap tile fills a CU's LDS once: 2 waves per SIMD
+__global__ void __launch_bounds__(CV_NT, KP > 32 ? 2 : sizeof(T) == 4 ? CV_MINW_F32 : 4)   // the 80-tap tile fills a CU's LDS once: 2 waves per SIMD; the float 32-tap one fits three times
 k_conv_rows(FitK g, const T* __restrict__ iunif,
             const int* __restrict__ cellx, const double* __restrict__ fracx,
             const int* __restrict__ celly, const double* __restrict__ fracy,
@@ -3793,9 +3793,9 @@ const void* fused_instance(int variant, bool direct, bool fixed, bool multi = tr
 // windows, or 80 padded taps of a K <= 77 beam on 48-row windows (its 32 row groups hold every row
 // with image data)
 static bool rows_kernel(const slamhip_ctx* c, int fz_rank) {
-  if (fz_rank != 1 || c->f32 || c->conv_mode == 4) return false;
+  if (fz_rank != 1 || c->conv_mode == 4) return false;
   return (c->fz_variant == 0 && c->sep_fixed) ||
-         (c->fz_variant == 3 && c->kpad == 80 && c->k.kbeam <= 77);
+         (c->fz_variant == 3 && !c->f32 && c->kpad == 80 && c->k.kbeam <= 77);
 }
 
 template <typename T>
@@ -4142,6 +4142,11 @@ int slamhip_create(const slamhip_desc* d, slamhip_ctx** out) {
         HIP_TRY(c, hipFuncSetAttribute((const void*)k_conv_rows<double, false>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->fz_lds));
         HIP_TRY(c, hipFuncSetAttribute((const void*)k_conv_rows<double, true>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->fz_lds));
+      } else {
+        HIP_TRY(c, hipFuncSetAttribute((const void*)k_conv_rows<float, false>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->fz_lds));
+        HIP_TRY(c, hipFuncSetAttribute((const void*)k_conv_rows<float, true>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->fz_lds));
       }
     }

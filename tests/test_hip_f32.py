@@ -68,6 +68,11 @@ def test_c2_f32_matches_f64():
         assert np.array_equal(f.data, data)
         got = f.chi2_batch(P)
         np.testing.assert_allclose(got, ref, rtol=TOL)
+        # the row-owning kernel (default) and the phase kernel (conv mode 4) do the same float
+        # operations in the same order per output
+        f.engine.set_conv_mode(4)
+        assert np.array_equal(f.chi2_batch(P), got)
+        f.engine.set_conv_mode(0)
         iu = f.engine.iunif(P[3])
         if tol_cube:
             assert _golden.relmax(iu, iu64) < tol_cube
