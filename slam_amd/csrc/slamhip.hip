@@ -1286,6 +1286,8 @@ k_compact(FitK g, const unsigned char* __restrict__ winflag, int total,
       out[2 * ax + 1] = (int)((w.fstep[ax] > 0 ? 1u : 0u) | ((unsigned)ja << 8) | ((unsigned)jb << 16) | 0x80000000u);
     }
     D->ixa = out[0]; D->ixb = out[1]; D->jya = out[2]; D->jyb = out[3];
+  } else if (!tile_ix) {                                  // windows on the observed grid itself (k_conv_rows<OBS>)
+    D->ixa = D->ixb = D->jya = D->jyb = 0;
   } else {
     D->ixa = tile_ix[((long long)wi * wnx + tbx) * 2];
     D->ixb = tile_ix[((long long)wi * wnx + tbx) * 2 + 1];
@@ -1990,7 +1992,7 @@ __device__ __forceinline__ void row_round(T* tile, const unsigned char* rowlist,
 // nothing any other wave touches, so none of this needs a barrier.  One barrier before the column
 // pass (which reads every wave's rows) and one after the sums are left.  Same arithmetic, same
 // order of operations per output as k_conv_chi2's fixed-pitch instance: chi2 is bitwise the same.
-template <typename T, bool REGRID, int TY = 64, int KP = 32>
+template <typename T, bool REGRID, int TY = 64, int KP = 32, bool OBS = false>
 __global__ void __launch_bounds__(CV_NT, KP > 32 ? 2 : sizeof(T) == 4 ? CV_MINW_F32 : 4)   // the 80-tap tile fills a CU's LDS once: 2 waves per SIMD; the float 32-tap one fits three times
 k_conv_rows(FitK g, const T* __restrict__ iunif,
             const int* __restrict__ cellx, const double* __restrict__ fracx,
@@ -1998,7 +2000,15 @@ k_conv_rows(FitK g, const T* __restrict__ iunif,
             const WinDesc* __restrict__ list, int* __restrict__ count, int wnx, int wny,
             double* __restrict__ partial,
             const T* __restrict__ gxp, const T* __restrict__ gyp,
-            const T* __restrict__ gxw, const T* __restrict__ gyw, int tail4_arg, int rev_total) {
+            const T* __restrict__ gxw, const T* __restrict__ gyw, int tail4_arg, int rev_total,
+            const unsigned char* __restrict__ rowflag = nullptr) {
+  // OBS (the 'mom0*' scalings' batch path): `iunif` is the regridded, moment-scaled cube on the
+  // observed grid itself (g.nneed = nx = ny in the FitK copy this launch gets), windows tile it
+  // without overlap, plain beam taps, and a window leaves sum (data - model)^2 over its pixels
+  // (NaN terms dropped, :601) in partial[e].  k_regrid_mom0 stored only the 64-pixel row
+  // segments it marked in `rowflag`: what a staged tile holds outside them is stale and is
+  // not written to the LDS tile.
+  static_assert(!OBS || !REGRID, "the observed grid needs no regrid");
   // REGRID = false: every window of `list` belongs to a walker whose regrid is folded into the
   // beam taps (k_compact's first list): no conv tile, no bilinear phase, none of its state.
   // REGRID = true: the general form, run on k_compact's second list (the last *count entries
@@ -2111,7 +2121,7 @@ k_conv_rows(FitK g, const T* __restrict__ iunif,
     const int tby = (tb >> 8) & 0xff, tbx = tb & 0xff;
     const int wi = (int)((unsigned)tb >> 16), k = z - wi * g.nv;
     const T* src = iunif + (long long)z * n * n;
-    const int x0 = tbx * (TX - 1), y0 = tby * (TY - 1);
+    const int x0 = tbx * (OBS ? TX : TX - 1), y0 = tby * (OBS ? TY : TY - 1);
     const int wx0 = x0 - ng, wy0 = y0 - ng;
     const int ftx0 = max(wx0, 0) / PT_X, fty0 = max(wy0, 0) / PT_Y;
     const int fnx = min(wx0 + vcols - 1, n - 1) / PT_X - ftx0 + 1;
@@ -2124,7 +2134,8 @@ k_conv_rows(FitK g, const T* __restrict__ iunif,
     const int fxw = head(2), fyw = head(4);
     const bool fold_w = !REGRID || fxw < 0;                 // block-uniform
     const int fja = (fxw >> 8) & 255, fjb = (fxw >> 16) & 255;
-    const int pixx = (fold_w && lane >= fja && lane < fjb) ? head(1) + ((fxw & 1) ? lane : -lane) : -1;
+    const int pixx = OBS ? (x0 + lane < g.nx ? x0 + lane : -1)
+                         : (fold_w && lane >= fja && lane < fjb) ? head(1) + ((fxw & 1) ? lane : -lane) : -1;
     const int woff = wx0 & 1;
     T* tile = lds + woff;
     auto head64 = [&](int i) {
@@ -2148,6 +2159,8 @@ k_conv_rows(FitK g, const T* __restrict__ iunif,
     unsigned sok = 0u;                                      // bit NFX gi + fx: this lane holds a pair there
     unsigned uocc = 0u;                                     // wave-uniform, same bits: the tile half holds emission
     unsigned m16 = 0u;                                      // bit 4 gi + i: that owned row holds emission
+    unsigned segm = 0u;                                     // OBS: bit 4 gi + j: segment seg0 + j of this lane's row was stored
+    const int nseg = (g.nx + 63) >> 6, seg0 = max(wx0, 0) >> 6;
 #pragma unroll
     for (int gi = 0; gi < NG; ++gi) {
       const int q = 8 * gi + ((wv - gi) & 7);
@@ -2176,6 +2189,14 @@ k_conv_rows(FitK g, const T* __restrict__ iunif,
       const unsigned lanem = (r >= 0 && r < vrows && irow < n) ? (colm & rowocc) : 0u;
       sok |= lanem << (NFX * gi);
       const T* rp = src + ((long long)irow * n + (ftx0 * PT_X + scol));
+      if constexpr (OBS) {
+        if (rowocc && lanem) {
+          const unsigned char* rf = rowflag + ((long long)z * n + irow) * nseg + seg0;
+#pragma unroll
+          for (int j = 0; j < 3; ++j)
+            if (seg0 + j < nseg && rf[j]) segm |= 1u << (4 * gi + j);
+        }
+      }
 #pragma unroll
       for (int fx = 0; fx < NFX; ++fx)
         sv[gi][fx] = Real<T>::make2((T)0, (T)0);         // (left uninitialised the compiler's code is 35 % slower)
@@ -2227,7 +2248,9 @@ k_conv_rows(FitK g, const T* __restrict__ iunif,
       if ((uocc >> (NFX * gi)) & ((1u << NFX) - 1u)) {      // wave-uniform
 #pragma unroll
         for (int fx = 0; fx < NFX; ++fx) {
-          if ((sok >> (NFX * gi + fx)) & 1u) {
+          bool wr = (sok >> (NFX * gi + fx)) & 1u;
+          if constexpr (OBS) wr = wr && ((segm >> (4 * gi + ((ftx0 + fx) >> 1) - seg0)) & 1u);
+          if (wr) {
             ob[fx * PT_X] = sv[gi][fx].x;
             ob[fx * PT_X + 1] = sv[gi][fx].y;
           }
@@ -2239,11 +2262,11 @@ k_conv_rows(FitK g, const T* __restrict__ iunif,
 #pragma unroll
     for (int r = 0; r < RO; ++r) fdv[r] = 0.0;
     if (fold_w) {
-      const int ya = (fyw >> 8) & 255, yb = (fyw >> 16) & 255;
+      const int ya = OBS ? 0 : (fyw >> 8) & 255, yb = OBS ? min(TY, g.ny - y0) : (fyw >> 16) & 255;
       const int rlo = max(ya - wv * RO, 0), rhi = min(yb - wv * RO, RO);
       if (rhi > rlo) fvalid = ((1u << rhi) - 1u) & ~((1u << rlo) - 1u);
-      const long long step = (fyw & 1) ? (long long)g.nx : -(long long)g.nx;
-      const double* rowp = dat + (long long)(head(3) + ((fyw & 1) ? wv * RO : -(wv * RO))) * g.nx;
+      const long long step = (OBS || (fyw & 1)) ? (long long)g.nx : -(long long)g.nx;
+      const double* rowp = dat + (long long)(OBS ? y0 + wv * RO : head(3) + ((fyw & 1) ? wv * RO : -(wv * RO))) * g.nx;
       if (pixx >= 0) {
 #pragma unroll
         for (int r = 0; r < RO; ++r) {
@@ -2255,8 +2278,8 @@ k_conv_rows(FitK g, const T* __restrict__ iunif,
 
     STAMP(2);
     // -- 3. row pass over the owned rows with emission, results in place (this wave's rows only)
-    const T* __restrict__ wxr = fold_w ? gxw + (long long)wi * KP : gxp;
-    const T* __restrict__ wyr = fold_w ? gyw + (long long)wi * KP : gyp;
+    const T* __restrict__ wxr = (fold_w && !OBS) ? gxw + (long long)wi * KP : gxp;
+    const T* __restrict__ wyr = (fold_w && !OBS) ? gyw + (long long)wi * KP : gyp;
     // A round takes up to 8 listed rows (8 lanes per row, R outputs per lane) and writes its results
     // back in place at once: its lanes have all read their rows by then, and the next round reads
     // other rows.  A remainder of 3-4 rows runs 16 lanes per row with R / 2 outputs each, one of 1-2
@@ -2322,9 +2345,16 @@ k_conv_rows(FitK g, const T* __restrict__ iunif,
     if (fold_w) {
 #pragma unroll
       for (int r = 0; r < RO; ++r) {
-        const double av = (pixx >= 0 && ((fvalid >> r) & 1u)) ? (double)acc[r] : 0.0;
-        gf = fma(av, fdv[r], gf);
-        ff = fma(av, av, ff);
+        if constexpr (OBS) {
+          if (pixx >= 0 && ((fvalid >> r) & 1u)) {
+            const double dd = fdv[r] - (double)acc[r], qq = dd * dd;
+            if (qq == qq) gf += qq;                         // nansum (:601)
+          }
+        } else {
+          const double av = (pixx >= 0 && ((fvalid >> r) & 1u)) ? (double)acc[r] : 0.0;
+          gf = fma(av, fdv[r], gf);
+          ff = fma(av, av, ff);
+        }
       }
     } else if constexpr (REGRID) {
       // conv tile + bilinear regrid, as k_conv_chi2
@@ -2396,9 +2426,13 @@ k_conv_rows(FitK g, const T* __restrict__ iunif,
       double av = 0.0, b2 = 0.0;
 #pragma unroll
       for (int q = 0; q < CV_NW; ++q) { av += sg[q]; b2 += sf[q]; }
-      partial[3 * (long long)e] = av;
-      partial[3 * (long long)e + 1] = b2;
-      partial[3 * (long long)e + 2] = 1.0;
+      if constexpr (OBS) {
+        partial[e] = av;
+      } else {
+        partial[3 * (long long)e] = av;
+        partial[3 * (long long)e + 1] = b2;
+        partial[3 * (long long)e + 2] = 1.0;
+      }
     }
     it = nxt;
     if (nxt + 1 < nend) nxt = nxt + 1;                      // still inside the batch
@@ -2707,7 +2741,12 @@ k_regrid_mom0(FitK g, const int* __restrict__ cellx, const double* __restrict__ 
               const double* __restrict__ iunif, const unsigned char* __restrict__ flags,
               const int2* __restrict__ krange, int ftx, int fty, double* __restrict__ cube,
               unsigned char* __restrict__ tileflag, int tile_ty, int ntx, int nty,
-              unsigned char* __restrict__ rowflag) {
+              unsigned char* __restrict__ rowflag,
+              unsigned char* __restrict__ oflags, int oftx, int ofty,
+              unsigned char* __restrict__ owin, int ownx, int owny) {
+  // oflags / owin (with rowflag; may be null): the occupancy bytes of the observed cube in
+  // k_profile's form -- [walker][channel][32x8 pixel tile] -- and the 64 x 64 beam windows whose
+  // halo holds a lit pixel, for k_compact + k_conv_rows<OBS> (the batch path of one-term beams)
   const long long npix = (long long)g.ny * g.nx;
   const int lane = threadIdx.x & 63;
   const int jy = blockIdx.y * 4 + (threadIdx.x >> 6);
@@ -2813,8 +2852,19 @@ k_regrid_mom0(FitK g, const int* __restrict__ cellx, const double* __restrict__ 
       }
       const bool lit = v != 0.0;
       if (rf) {
-        if (__ballot(lit) == 0ull) continue;       // nothing of this wave in channel k
+        const unsigned long long lb = __ballot(lit);
+        if (lb == 0ull) continue;                  // nothing of this wave in channel k
         if (lane == 0) rf[(long long)k * g.ny * gridDim.x] = 1;
+        if (oflags && (lane & 31) == 0 && ((lb >> lane) & 0xffffffffull)) {
+          // this half wave's 32 pixels are one tile row of tile (jy / 8, px0 / 32)
+          const int px0 = blockIdx.x * 64 + lane, ngb = g.ngauss;
+          const long long zk = (long long)wi * g.nv + k;
+          oflags[zk * oftx * ofty + (jy / PT_Y) * oftx + px0 / PT_X] = 1;
+          const int bx0 = max(px0 - ngb, 0) / CONV_TX, bx1 = min(ownx - 1, (px0 + PT_X - 1 + ngb) / CONV_TX);
+          const int by0 = max(jy - ngb, 0) / 64, by1 = min(owny - 1, (jy + ngb) / 64);
+          for (int by = by0; by <= by1; ++by)
+            for (int bx = bx0; bx <= bx1; ++bx) owin[(zk * owny + by) * ownx + bx] = 1;
+        }
       }
       if (valid) c[(long long)k * npix] = v;
       if (fl && lit) fl[(long long)k * ntx * nty] = 1;
@@ -3133,17 +3183,42 @@ k_conv_obs_live(FitK g, const double* __restrict__ in, double* __restrict__ part
   }
 }
 
+// k_obs_empty: sum of data^2 (NaN terms dropped) over each 64 x 64 window of each channel: the
+// residual sum of a window whose model is zero.  One workgroup per (window, channel), once per fit.
+__global__ void __launch_bounds__(256)
+k_obs_empty(FitK g, int wnx, int wny, double* __restrict__ empty) {
+  __shared__ double sa[4];
+  const int bx = blockIdx.x % wnx, by = blockIdx.x / wnx, k = blockIdx.y;
+  const double* d = g.data + (long long)k * g.ny * g.nx;
+  double a = 0.0;
+  for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+    const int gx = bx * 64 + (e & 63), gy = by * 64 + (e >> 6);
+    if (gx < g.nx && gy < g.ny) {
+      const double v = d[(long long)gy * g.nx + gx], q = v * v;
+      if (q == q) a += q;
+    }
+  }
+  a = wave_sum(a);
+  if ((threadIdx.x & 63) == 0) sa[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) empty[(long long)k * wnx * wny + blockIdx.x] = (sa[0] + sa[1]) + (sa[2] + sa[3]);
+}
+
 // k_sum_chi2: one block per walker, fixed-order sum of its residual partials,
 // chi2 = sum / sigma^2 / pixperbeam (:601-602).  stats = {nan, nan, nan, chi2, 0, nblk}
 // (the mom0 scalings have no global amplitude).
 __global__ void __launch_bounds__(256)
 k_sum_chi2(FitK g, const double* __restrict__ partial, int nblk,
-           double* __restrict__ stats, double* __restrict__ chi2_out) {
+           double* __restrict__ stats, double* __restrict__ chi2_out,
+           const unsigned char* __restrict__ winflag = nullptr, const double* __restrict__ empty = nullptr) {
+  // winflag / empty (k_conv_rows<OBS>): windows without emission were never run; their residual
+  // sum is the fit's sum of data^2 there (`empty`, [channel][window], once per fit)
   __shared__ double sa[4];
   const int wi = blockIdx.x;
   const double* p = partial + (long long)wi * nblk;
+  const unsigned char* wf = winflag ? winflag + (long long)wi * nblk : nullptr;
   double a = 0.0;
-  for (int q = threadIdx.x; q < nblk; q += 256) a += p[q];
+  for (int q = threadIdx.x; q < nblk; q += 256) a += (!wf || wf[q]) ? p[q] : empty[q];
   a = wave_sum(a);
   if ((threadIdx.x & 63) == 0) sa[threadIdx.x >> 6] = a;
   __syncthreads();
@@ -3277,6 +3352,14 @@ struct slamhip_ctx {
   size_t ob_lds = 0;
   unsigned char* d_obflag = nullptr;  // [walker][nv][tiles] emission under k_conv_obs_sep tiles
   double* d_obempty = nullptr;        // [nv][tiles] residual sum of an empty tile (= sum data^2)
+  // the batch path of one-term beams (k_compact + k_conv_rows<OBS> on the observed grid)
+  bool ob_rows = false;
+  int ob_wnx = 0, ob_wny = 0, ob_ftx = 0, ob_fty = 0;
+  unsigned char* d_oflags = nullptr;  // [walker][nv][32x8 tiles of the observed grid] occupancy
+  unsigned char* d_owin = nullptr;    // [walker][nv][64x64 windows] emission under the window's halo
+  WinDesc* d_odesc = nullptr;         // descriptors of the windows with emission
+  int* d_ocount = nullptr;            // LIVECOUNT_WORDS counters / tickets
+  double* d_oempty = nullptr;         // [nv][window] sum of data^2 over the window's pixels
   int ob_nty = 0;
   int ftx = 1, fty = 1;
   int persist_blocks = 1;
@@ -3693,8 +3776,13 @@ int run_group_mom0(slamhip_ctx* c, Scratch& S, const double* d_params, int nw, d
     Timed t_(c, KID_REGRID, st);
     const long long npix = (long long)k.ny * k.nx;
     const bool flagged = c->ob_ty && c->conv_mode != 1 && convolving;
+    const bool rows_path = flagged && c->ob_rows && !d_model && c->conv_mode != 4;
     if (flagged)
       HIP_TRY(c, hipMemsetAsync(c->d_obflag, 0, (size_t)nw * k.nv * c->ob_grid.x * c->ob_nty, st));
+    if (rows_path) {
+      HIP_TRY(c, hipMemsetAsync(c->d_oflags, 0, (size_t)nw * k.nv * c->ob_ftx * c->ob_fty, st));
+      HIP_TRY(c, hipMemsetAsync(c->d_owin, 0, (size_t)nw * k.nv * c->ob_wnx * c->ob_wny, st));
+    }
     const int ntile = c->ftx * c->fty;
     hipLaunchKernelGGL(k_tile_krange, dim3((ntile + 255) / 256, nw), dim3(256), 0, st, k, S.flags,
                        ntile, c->d_krange);
@@ -3705,11 +3793,41 @@ int run_group_mom0(slamhip_ctx* c, Scratch& S, const double* d_params, int nw, d
                        S.cellx, S.fracx, S.celly, S.fracy, (const double*)S.iunif, S.flags,
                        c->d_krange, c->ftx, c->fty, c->d_obs, flagged ? c->d_obflag : (unsigned char*)nullptr,
                        c->ob_ty ? c->ob_ty : 1, (int)c->ob_grid.x, c->ob_nty,
-                       flagged ? c->d_rowflag : (unsigned char*)nullptr);
+                       flagged ? c->d_rowflag : (unsigned char*)nullptr,
+                       rows_path ? c->d_oflags : (unsigned char*)nullptr, c->ob_ftx, c->ob_fty,
+                       rows_path ? c->d_owin : (unsigned char*)nullptr, c->ob_wnx, c->ob_wny);
   }
   if (!convolving) {       // peaktounity on the observed grid (:531-532), single-vector product
     hipLaunchKernelGGL(k_peak_unity, dim3(k.nv * nw), dim3(256), 0, st, k, c->d_obs, d_model,
                        (long long)k.ny * k.nx);
+    HIP_TRY(c, hipGetLastError());
+    return SLAMHIP_OK;
+  }
+  if (c->ob_ty && c->ob_rows && !d_model && c->conv_mode != 1 && c->conv_mode != 4) {
+    // batch path, one-term beam of <= 32 padded taps on a square observed grid: the windows with
+    // emission listed with their tile bitmaps (k_compact, as for the 'uniform' scaling), then
+    // the row-owning beam kernel on them; conv mode 4 keeps the older tile kernel below
+    const int nwin = nw * k.nv * c->ob_wnx * c->ob_wny;
+    FitK ko = k;
+    ko.nneed = k.nx;                                        // the "model grid" of these kernels is the observed one
+    {
+      Timed t_(c, KID_COMPACT, st);
+      HIP_TRY(c, hipMemsetAsync(c->d_ocount, 0, LIVECOUNT_WORDS * sizeof(int), st));
+      hipLaunchKernelGGL(k_compact, dim3((nwin + 255) / 256), dim3(256), 0, st, ko, c->d_owin, nwin,
+                         c->d_oflags, c->ob_ftx, c->ob_fty, (const int*)nullptr, (const int*)nullptr,
+                         c->ob_wnx, c->ob_wny, CONV_TX, 64, 64, c->d_odesc, c->d_ocount, S.wk, 0);
+    }
+    {
+      Timed t_(c, KID_CONV, st);
+      const int tail4 = k.kbeam <= c->kpad - CONV_R / 2 ? 1 : 0;
+      hipLaunchKernelGGL((k_conv_rows<double, false, 64, 32, true>), dim3(c->persist_blocks), dim3(CV_NT), c->fz_lds,
+                         st, ko, (const double*)c->d_obs, S.cellx, S.fracx, S.celly, S.fracy, c->d_odesc,
+                         c->d_ocount, c->ob_wnx, c->ob_wny, S.partial, k.gx_pad, k.gy_pad, k.gx_pad, k.gy_pad,
+                         tail4, 0, c->d_rowflag);
+    }
+    Timed t2_(c, KID_FINALIZE, st);
+    hipLaunchKernelGGL(k_sum_chi2, dim3(nw), dim3(256), 0, st, k, S.partial, k.nv * c->ob_wnx * c->ob_wny,
+                       S.stats, d_chi2, c->d_owin, c->d_oempty);
     HIP_TRY(c, hipGetLastError());
     return SLAMHIP_OK;
   }
@@ -4327,6 +4445,29 @@ int slamhip_create(const slamhip_desc* d, slamhip_ctx** out) {
       const int per = std::max(1, std::min(8, (int)((160 * 1024) / (c->ob_lds + 1024))));
       c->ob_persist = pr.multiProcessorCount * per;
     }
+    // the row-owning batch path: one-term beam, 32 padded taps (the 64-row tile twice per CU),
+    // square observed grid of even size (the kernels index one `n`, and stage pixel pairs)
+    if (c->d_oblist && c->nrank == 1 && c->fz_variant == 0 && c->kpad == 32 && !c->f32 &&
+        k.nx == k.ny && k.nx % 2 == 0 && k.nx >= 64) {
+      c->ob_wnx = (k.nx + 63) / 64;
+      c->ob_wny = (k.ny + 63) / 64;
+      c->ob_ftx = (k.nx + PT_X - 1) / PT_X;
+      c->ob_fty = (k.ny + PT_Y - 1) / PT_Y;
+      const size_t nwn = (size_t)c->ob_wnx * c->ob_wny;
+      if (W * k.nv * nwn < (size_t)1 << 30 && c->ob_wnx <= 255 && c->ob_wny <= 255 &&
+          nwn * k.nv <= c->max_blocks * 3) {
+        if ((rc = dev_alloc(c, &c->d_oflags, W * k.nv * c->ob_ftx * c->ob_fty + 64))) return rc;
+        if ((rc = dev_alloc(c, &c->d_owin, W * k.nv * nwn))) return rc;
+        if ((rc = dev_alloc(c, &c->d_odesc, W * k.nv * nwn))) return rc;
+        if ((rc = dev_alloc(c, &c->d_ocount, LIVECOUNT_WORDS))) return rc;
+        if ((rc = dev_alloc(c, &c->d_oempty, (size_t)k.nv * nwn))) return rc;
+        hipLaunchKernelGGL(k_obs_empty, dim3((unsigned)nwn, k.nv), dim3(256), 0, c->stream, k, c->ob_wnx,
+                           c->ob_wny, c->d_oempty);
+        HIP_TRY(c, hipFuncSetAttribute((const void*)k_conv_rows<double, false, 64, 32, true>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->fz_lds));
+        c->ob_rows = true;
+      }
+    }
     HIP_TRY(c, hipMemsetAsync(c->d_obs, 0, ncube * sizeof(double), c->stream));
     dim3 g(c->ob_grid.x, c->ob_nty, k.nv);
 #define SLAM_OBS0(TY_, NIT_)                                                                 \
@@ -4745,6 +4886,9 @@ int slamhip_group_counts(slamhip_ctx* c, int nw, int64_t* out) {
       hipLaunchKernelGGL(k_count_windows, dim3(512), dim3(256), 0, c->stream, S.livelist, S.livecount + 3,
                          ty, c->kpad, rb, cnt, (int)(c->fz_grid.x * c->fz_grid.y * c->fz_grid.z) * nw);
   }
+  if (mom0 && c->ob_rows && c->conv_mode != 4)             // the row-owning kernel's windows on the observed grid
+    hipLaunchKernelGGL(k_count_windows, dim3(512), dim3(256), 0, c->stream, c->d_odesc, c->d_ocount,
+                       64, c->kpad, CONV_R, cnt, 0);
   hipLaunchKernelGGL(k_count_flags, dim3(1024), dim3(256), 0, c->stream, S.flags,
                      (long long)nw * k.nv * c->ftx * c->fty, S.gflag, (long long)nw * (k.nslot >> 6), cnt);
   if (c->g32)
@@ -4759,7 +4903,7 @@ int slamhip_group_counts(slamhip_ctx* c, int nw, int64_t* out) {
   rc = single_finish(c, e, "group_counts");
   if (rc) return rc;
   for (int i = 0; i < 8; ++i) out[i] = (int64_t)h[i];
-  if (mom0) {     // 'mom0*' scalings: the beam windows with emission that k_obs_list listed for the last group
+  if (mom0 && !(c->ob_rows && c->conv_mode != 4)) {     // 'mom0*' scalings: the beam windows with emission that k_obs_list listed for the last group
     int live = 0;
     HIP_TRY(c, hipMemcpy(&live, c->d_obcount, sizeof live, hipMemcpyDeviceToHost));
     out[0] = live;

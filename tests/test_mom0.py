@@ -166,6 +166,43 @@ def test_gpu_sparse_path_equals_dense_on_a_multi_segment_image():
         fit.close()
 
 
+@pytest.mark.gpu
+def test_gpu_row_owning_beam_kernel_on_the_observed_grid():
+    """One-term beam of 25..32 padded taps on a square observed grid: the batch path lists the
+    64 x 64 windows with emission (k_compact) and runs the row-owning beam kernel on them
+    (k_conv_rows<OBS>: only the stored row segments of a staged tile are used).  Against the
+    older tile kernel (conv mode 4), the dense direct taps (mode 1) and the single-vector
+    product; offsets push emission across window and image edges."""
+    from slam_amd import synth
+    fit = synth.make_fit(None, N=256, NV=16, beam_px=(8, 6), scaling='mom0ft')
+    try:
+        eng = fit.engine
+        P = np.concatenate([synth.walkers(9), synth.walkers(3, workload='dense_disk')])
+        P[:, 0] *= 0.3                          # keep the emission inside the 16 channels
+        P[1, 8], P[1, 9] = 35.0, -20.0
+        P[2, 8], P[2, 9] = -150.0, 120.0
+        P[3, 10] = 0.3
+        P[4, 1] = 400.0
+        chi2 = fit.chi2_batch(P)
+        counts = eng.group_counts(len(P))
+        assert counts['live_windows'] > 0 and counts['window_tiles'] > 0 and counts['window_rows'] > 0   # the list carries tile bitmaps and row masks
+        assert np.all(np.isfinite(chi2)) and len(set(chi2.tolist())) == len(P)
+        assert np.array_equal(fit.chi2_batch(P[::-1])[::-1], chi2)
+        assert np.array_equal(np.array([fit.chi2_batch(p[None])[0] for p in P]), chi2)
+        eng.set_conv_mode(4)
+        tile = fit.chi2_batch(P)
+        eng.set_conv_mode(1)
+        dense = fit.chi2_batch(P)
+        eng.set_conv_mode(0)
+        np.testing.assert_allclose(chi2, tile, rtol=1e-11)
+        np.testing.assert_allclose(chi2, dense, rtol=1e-11)
+        for i in (0, 2, 10):
+            _, st = eng.cubemodel(P[i], return_stats=True)
+            assert st['chi2'] == pytest.approx(chi2[i], rel=1e-11)
+    finally:
+        fit.close()
+
+
 # ---------------------------------------------------------------------------
 # Moment maps behind plotmom (SURVEY.md 8f-4): golden vectors recorded from the
 # reference's makemom01 by tests/golden/make_golden_moments.py.
