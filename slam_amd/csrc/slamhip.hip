@@ -2711,17 +2711,55 @@ k_count_hits(FitK g, const WalkerK* __restrict__ wk, const T2* __restrict__ geom
 // k_tile_krange: per (walker, Iunif tile) the channel range [lo, hi) in which
 // k_profile lit the tile (lo = nv, hi = 0 for a tile that stayed dark), so that
 // k_regrid_mom0 visits only channels that can hold emission under a pixel.
+// kmask[walker][tile][(nv + 31) / 32]: the same occupancy as one bit per channel (k_regrid_mom0
+// asks for a word per 32 channels and corner instead of a byte per channel and corner).
 __global__ void __launch_bounds__(256)
 k_tile_krange(FitK g, const unsigned char* __restrict__ flags, int ntile,
-              int2* __restrict__ krange) {
+              int2* __restrict__ krange, unsigned* __restrict__ kmask) {
   const int t = blockIdx.x * 256 + threadIdx.x;
   if (t >= ntile) return;
   const int wi = blockIdx.y;
   const unsigned char* f = flags + (long long)wi * g.nv * ntile + t;
+  const int nword = (g.nv + 31) >> 5;
+  unsigned* km = kmask + ((long long)wi * ntile + t) * nword;
   int lo = g.nv, hi = 0;
-  for (int k = 0; k < g.nv; ++k)
-    if (f[(long long)k * ntile]) { lo = min(lo, k); hi = k + 1; }
+  for (int k0 = 0; k0 < g.nv; k0 += 32) {
+    unsigned word = 0u;
+    for (int k = k0; k < min(k0 + 32, g.nv); ++k)
+      if (f[(long long)k * ntile]) { lo = min(lo, k); hi = k + 1; word |= 1u << (k - k0); }
+    km[k0 >> 5] = word;
+  }
   krange[(long long)wi * ntile + t] = make_int2(lo, hi);
+}
+
+// k_mom_model: the model's moment on its own grid, M[j][i] = sum_k Iunif[k][j][i] over the lit
+// channels of the pixel's tile (one workgroup per 32x8 tile and walker; every pixel is written,
+// dark tiles with 0).  The regrid is linear, so the moment of the regridded cube (:521) is the
+// regridded M: k_regrid_mom0 then reads Iunif once instead of twice.
+__global__ void __launch_bounds__(256)
+k_mom_model(FitK g, const double* __restrict__ iunif, const unsigned char* __restrict__ flags,
+            const int2* __restrict__ krange, int ftx, int fty, double* __restrict__ mom) {
+  const int tile = blockIdx.x, wi = blockIdx.y;
+  const int ntile = ftx * fty, n = g.nneed;
+  const int tby = tile / ftx, tbx = tile - tby * ftx;
+  const int x = tbx * PT_X + (threadIdx.x & (PT_X - 1)), y = tby * PT_Y + threadIdx.x / PT_X;
+  if (x >= n || y >= n) return;
+  const int2 kr = krange[(long long)wi * ntile + tile];     // block-uniform
+  const unsigned char* f = flags + (long long)wi * g.nv * ntile + tile;
+  const double* src = iunif + ((long long)wi * g.nv * n + y) * n + x;
+  const long long plane = (long long)n * n;
+  double a = 0.0;
+  int k = kr.x;
+  for (; k + 4 <= kr.y; k += 4) {                           // four channels in flight
+    double v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = f[(long long)(k + u) * ntile] ? src[(k + u) * plane] : 0.0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) a += v[u];
+  }
+  for (; k < kr.y; ++k)
+    if (f[(long long)k * ntile]) a += src[k * plane];
+  mom[(long long)wi * plane + (long long)y * n + x] = a;
 }
 
 // k_regrid_mom0: regrid (:475-483) and per-pixel moment-0 scale (:521-525) in
@@ -2743,7 +2781,8 @@ k_regrid_mom0(FitK g, const int* __restrict__ cellx, const double* __restrict__ 
               unsigned char* __restrict__ tileflag, int tile_ty, int ntx, int nty,
               unsigned char* __restrict__ rowflag,
               unsigned char* __restrict__ oflags, int oftx, int ofty,
-              unsigned char* __restrict__ owin, int ownx, int owny) {
+              unsigned char* __restrict__ owin, int ownx, int owny,
+              const double* __restrict__ mom, const unsigned* __restrict__ kmask) {
   // oflags / owin (with rowflag; may be null): the occupancy bytes of the observed cube in
   // k_profile's form -- [walker][channel][32x8 pixel tile] -- and the 64 x 64 beam windows whose
   // halo holds a lit pixel, for k_compact + k_conv_rows<OBS> (the batch path of one-term beams)
@@ -2782,15 +2821,25 @@ k_regrid_mom0(FitK g, const int* __restrict__ cellx, const double* __restrict__ 
   // channel; the caller drops them): all flag bytes, then all four corners of
   // every channel whatever its flags say, so that one memory round trip serves
   // RG_U channels; corners in unlit tiles hold old data and are dropped here.
-  constexpr int RG_U = 4;
+  constexpr int RG_U = 4;                          // (2 and 8 measured: 50.2 / 49.2 instead of 46.4 us/eval)
+  // the four corner tiles' occupancy words of the 32-channel block in hand (k0 is wave-uniform
+  // and a multiple of RG_U, so a group of RG_U channels lies in one word)
+  const int nword = (g.nv + 31) >> 5;
+  int curw = -1;
+  unsigned wa = 0u, wb = 0u, wc = 0u, wd = 0u;
   auto values = [&](int k0, double* out) {
-    unsigned char fa[RG_U], fb[RG_U], fc[RG_U], fd[RG_U];
+    bool fa[RG_U], fb[RG_U], fc[RG_U], fd[RG_U];
     double l00[RG_U], l01[RG_U], l10[RG_U], l11[RG_U];
+    if ((k0 >> 5) != curw) {
+      curw = k0 >> 5;
+      const unsigned* km = kmask + (long long)wi * ntile * nword + curw;
+      wa = km[(long long)ta * nword]; wb = km[(long long)tb * nword];
+      wc = km[(long long)tc * nword]; wd = km[(long long)td * nword];
+    }
 #pragma unroll
     for (int u = 0; u < RG_U; ++u) {
-      const int kk = min(k0 + u, g.nv - 1);
-      const unsigned char* f = flags + ((long long)wi * g.nv + kk) * ntile;
-      fa[u] = f[ta]; fb[u] = f[tb]; fc[u] = f[tc]; fd[u] = f[td];
+      const int sh = (k0 + u) & 31;                // (k0 + u >= nv: the bit is 0)
+      fa[u] = (wa >> sh) & 1u; fb[u] = (wb >> sh) & 1u; fc[u] = (wc >> sh) & 1u; fd[u] = (wd >> sh) & 1u;
     }
 #pragma unroll
     for (int u = 0; u < RG_U; ++u) {
@@ -2806,13 +2855,11 @@ k_regrid_mom0(FitK g, const int* __restrict__ cellx, const double* __restrict__ 
                v10 * t0 * (1 - t1) + v11 * t0 * t1;   // scipy _rgi.py:478-482, as k_regrid
     }
   };
+  // the pixel's moment: k_mom_model's map regridded like a channel (dark tiles hold 0 there)
   double m0 = 0.0;
-  for (int k0 = klo; k0 < khi; k0 += RG_U) {
-    double v[RG_U];
-    values(k0, v);
-#pragma unroll
-    for (int u = 0; u < RG_U; ++u)
-      if (k0 + u < khi) m0 += v[u];
+  if (query) {
+    const double* mm = mom + ((long long)wi * n + c0) * n + c1;
+    m0 = mm[0] * (1 - t0) * (1 - t1) + mm[1] * (1 - t0) * t1 + mm[n] * t0 * (1 - t1) + mm[n + 1] * t0 * t1;
   }
   m0 = m0 * g.dv;
   if (m0 < 0.0) m0 = __builtin_nan("");
@@ -2836,7 +2883,7 @@ k_regrid_mom0(FitK g, const int* __restrict__ cellx, const double* __restrict__ 
     for (int k = 0; k < min(wlo, g.nv); ++k) c[(long long)k * npix] = 0.0;
     for (int k = max(whi, wlo); k < g.nv; ++k) c[(long long)k * npix] = 0.0;
   }
-  for (int k0 = wlo; k0 < whi; k0 += RG_U) {
+  for (int k0 = wlo & ~(RG_U - 1); k0 < whi; k0 += RG_U) {   // (channels below wlo come out 0 and are skipped)
     double vv[RG_U];
     values(k0, vv);
 #pragma unroll
@@ -3341,6 +3388,8 @@ struct slamhip_ctx {
   int iconv_walkers = 0;
   double* d_obs = nullptr;     // 'mom0*' scalings: [walker][nv][ny][nx] regridded cube
   int2* d_krange = nullptr;    // 'mom0*' scalings: [walker][Iunif tile] lit channel range
+  double* d_mom = nullptr;     // 'mom0*' scalings: [walker][n][n] moment of the model on its own grid
+  unsigned* d_kmask = nullptr; // 'mom0*' scalings: [walker][Iunif tile][nv / 32] lit channels, one bit each
   unsigned char* d_rowflag = nullptr;   // 'mom0*' scalings: [walker][nv][ny][nx/64] stored row segments
   int* d_oblist = nullptr;              // 'mom0*' scalings: beam windows with emission, count[2]
   int* d_obcount = nullptr;
@@ -3777,7 +3826,7 @@ int run_group_mom0(slamhip_ctx* c, Scratch& S, const double* d_params, int nw, d
     const long long npix = (long long)k.ny * k.nx;
     const bool flagged = c->ob_ty && c->conv_mode != 1 && convolving;
     const bool rows_path = flagged && c->ob_rows && !d_model && c->conv_mode != 4;
-    if (flagged)
+    if (flagged && !rows_path)
       HIP_TRY(c, hipMemsetAsync(c->d_obflag, 0, (size_t)nw * k.nv * c->ob_grid.x * c->ob_nty, st));
     if (rows_path) {
       HIP_TRY(c, hipMemsetAsync(c->d_oflags, 0, (size_t)nw * k.nv * c->ob_ftx * c->ob_fty, st));
@@ -3785,17 +3834,20 @@ int run_group_mom0(slamhip_ctx* c, Scratch& S, const double* d_params, int nw, d
     }
     const int ntile = c->ftx * c->fty;
     hipLaunchKernelGGL(k_tile_krange, dim3((ntile + 255) / 256, nw), dim3(256), 0, st, k, S.flags,
-                       ntile, c->d_krange);
+                       ntile, c->d_krange, c->d_kmask);
+    hipLaunchKernelGGL(k_mom_model, dim3(ntile, nw), dim3(256), 0, st, k, (const double*)S.iunif, S.flags,
+                       c->d_krange, c->ftx, c->fty, c->d_mom);
     const int nseg = (k.nx + 63) / 64;
     if (flagged)
       HIP_TRY(c, hipMemsetAsync(c->d_rowflag, 0, (size_t)nw * k.nv * k.ny * nseg, st));
     hipLaunchKernelGGL(k_regrid_mom0, dim3(nseg, (k.ny + 3) / 4, nw), dim3(256), 0, st, k,
                        S.cellx, S.fracx, S.celly, S.fracy, (const double*)S.iunif, S.flags,
-                       c->d_krange, c->ftx, c->fty, c->d_obs, flagged ? c->d_obflag : (unsigned char*)nullptr,
+                       c->d_krange, c->ftx, c->fty, c->d_obs, (flagged && !rows_path) ? c->d_obflag : (unsigned char*)nullptr,
                        c->ob_ty ? c->ob_ty : 1, (int)c->ob_grid.x, c->ob_nty,
                        flagged ? c->d_rowflag : (unsigned char*)nullptr,
                        rows_path ? c->d_oflags : (unsigned char*)nullptr, c->ob_ftx, c->ob_fty,
-                       rows_path ? c->d_owin : (unsigned char*)nullptr, c->ob_wnx, c->ob_wny);
+                       rows_path ? c->d_owin : (unsigned char*)nullptr, c->ob_wnx, c->ob_wny,
+                       (const double*)c->d_mom, (const unsigned*)c->d_kmask);
   }
   if (!convolving) {       // peaktounity on the observed grid (:531-532), single-vector product
     hipLaunchKernelGGL(k_peak_unity, dim3(k.nv * nw), dim3(256), 0, st, k, c->d_obs, d_model,
@@ -4372,7 +4424,12 @@ int slamhip_create(const slamhip_desc* d, slamhip_ctx** out) {
   const size_t nseg = (size_t)(k.nx + 63) / 64;
   // what one more walker costs: its share of the scratch set plus, for the 'mom0*'
   // scalings, its regridded cube and row-segment marks
-  const size_t mom0_walker = d->mom0decon ? ncube * sizeof(double) + (size_t)k.nv * k.ny * nseg : 0;
+  // (+ the model's moment map, and the observed cube's tile / window flags and window list)
+  const size_t mom0_walker = d->mom0decon
+      ? ncube * sizeof(double) + (size_t)k.nv * k.ny * nseg + (size_t)n * n * sizeof(double) +
+        (size_t)k.nv * (((k.nx + PT_X - 1) / PT_X) * ((k.ny + PT_Y - 1) / PT_Y) +
+                        ((k.nx + 63) / 64) * ((k.ny + 63) / 64) * (1 + sizeof(WinDesc)))
+      : 0;
   const size_t per_walker = carve(c, 1, nullptr, nullptr) + mom0_walker;
   size_t freeb = 0, totalb = 0;
   HIP_TRY(c, hipMemGetInfo(&freeb, &totalb));
@@ -4395,6 +4452,8 @@ int slamhip_create(const slamhip_desc* d, slamhip_ctx** out) {
   if ((rc = ensure_iconv(c, 1))) return rc;
   if (d->mom0decon && (rc = dev_alloc(c, &c->d_obs, W * ncube))) return rc;
   if (d->mom0decon && (rc = dev_alloc(c, &c->d_krange, W * (size_t)c->ftx * c->fty))) return rc;
+  if (d->mom0decon && (rc = dev_alloc(c, &c->d_mom, W * (size_t)n * n))) return rc;
+  if (d->mom0decon && (rc = dev_alloc(c, &c->d_kmask, W * (size_t)c->ftx * c->fty * ((k.nv + 31) / 32)))) return rc;
   if (d->mom0decon && (rc = dev_alloc(c, &c->d_rowflag, W * (size_t)k.nv * k.ny * nseg))) return rc;
   {
     // a conv window must not span more occupancy bytes than its LDS table holds
