@@ -204,12 +204,25 @@ def kernel_model(eng, fit, counts, itemsize=8, geomsize=8, scaling='uniform'):
             rb = 16 if ty == 64 else 8
             fl['k_conv'] = 2 * 64 * rb * 8 * K * counts['col_blocks'] * K / kpad
     else:
-        # 'mom0*': beam on the observed grid, dense inside every listed window (row pass over the
-        # window + halo rows, column pass over its rows), one pass pair per beam term
-        terms = max(rank, 1)
-        fl['k_conv'] = 2 * terms * counts['live_windows'] * tx * K * ((ty + K - 1) + ty)
-        # the regridded cube under the window + halo (marked segments; upper bound), data under it
-        by['k_conv'] = counts['live_windows'] * ((ty + K - 1) * (tx + K - 1) + ty * tx) * 8
+        # 'mom0*': the regridded, rescaled cube lives on the observed grid.  Its lit 32x8 tiles are
+        # not counted one by one; taken as the model's lit tiles scaled by the grids' pixel ratio
+        # (the same sky, regridded).
+        obs_tiles = counts['lit_planes'] * (eng.nx * eng.ny) / (eng.nneed * eng.nneed)
+        # k_mom_model + k_regrid_mom0: the lit Iunif tiles twice (moment, then the scaled
+        # output), the moment map written and read, the stored row segments written
+        by['k_regrid'] = 2 * counts['lit_planes'] * tile + W * eng.nneed**2 * 16 + obs_tiles * tile
+        fl['k_regrid'] = counts['lit_planes'] * 256 * 1 + obs_tiles * 256 * 10    # moment sum; bilinear + scale per stored value
+        if counts['window_rows'] > 0:
+            # row-owning beam kernel on the listed 64x64 windows (k_conv_rows<OBS>): as the
+            # 'uniform' path's model with the plain K taps
+            fl['k_conv'] = 2 * (counts['window_rows'] * tx * K + counts['col_blocks'] * 64 * 8 * 8 * K / kpad)
+            by['k_conv'] = obs_tiles * tile + counts['live_windows'] * (64 * 64 * 8 + 240)
+        else:
+            # older tile kernel (conv mode 4, beams it still serves): dense inside every listed
+            # window (row pass over the window + halo rows, column pass over its rows)
+            terms = max(rank, 1)
+            fl['k_conv'] = 2 * terms * counts['live_windows'] * tx * K * ((ty + K - 1) + ty)
+            by['k_conv'] = counts['live_windows'] * ((ty + K - 1) * (tx + K - 1) + ty * tx) * 8
     return by, fl
 
 

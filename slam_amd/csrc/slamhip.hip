@@ -712,6 +712,14 @@ k_plan(FitK g, const WalkerK* __restrict__ wk, const float2* __restrict__ grange
 // channel, 32x8 tile) gets an occupancy byte and only occupied tiles are
 // written.  Consumers either honour the flags (k_conv_chi2) or are handed a
 // pre-zeroed buffer (dense taps).
+#ifdef SLAMHIP_PHASE_STAMPS
+__device__ unsigned long long g_pstamp[8];      // k_profile's phases, cycles of wave 0 summed over items
+#define PSTAMP(p_) do { unsigned long long t_; __builtin_amdgcn_sched_barrier(0); \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); __builtin_amdgcn_sched_barrier(0); \
+    if (threadIdx.x == 0) atomicAdd(&g_pstamp[p_], t_ - pprev); pprev = t_; } while (0)
+#else
+#define PSTAMP(p_) do { } while (0)
+#endif
 // One listed (walker, tile, channel block) triple, by the whole 256-thread workgroup.
 template <bool FAST, typename T, typename TG>   // T: table and accumulators, TG: geometry entries
 __device__ __forceinline__ void
@@ -720,6 +728,10 @@ profile_item(const FitK& g, const WalkerK* __restrict__ wk, const typename Real<
              unsigned char* __restrict__ winflag, int wnx, int wny, int wsx, int wsy,
              const uint4* __restrict__ items, int it, T* s_prof, unsigned* s_mask) {
   using T2 = typename Real<TG>::vec2;
+#ifdef SLAMHIP_PHASE_STAMPS
+  unsigned long long pprev;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pprev) :: "memory");
+#endif
   // double geometry: the reference's table entry, bit for bit (lanes near a table
   // boundary redo the index in the reference's operation order); float geometry
   // cannot tell, its fast index is the index
@@ -762,7 +774,9 @@ profile_item(const FitK& g, const WalkerK* __restrict__ wk, const typename Real<
   for (int s = 0; s < 4; ++s)
     spec[s] = nl > 0 ? gw[(long long)s * g.nslot] : Real<TG>::make2(Real<TG>::masked, (TG)0);
 
+  PSTAMP(0);
   __syncthreads();                                        // s_prof ready
+  PSTAMP(1);
   {
     const int kf = cix * CH + tid;                        // flag writer: thread c -> channel c
     // a sample lights the block only if vlos + voff lies within hw of [cmin, cmax]
@@ -848,6 +862,7 @@ profile_item(const FitK& g, const WalkerK* __restrict__ wk, const typename Real<
     // tail, 2.4 us/eval): the kernel's scalars then stay live across the first item, the 16
     // scaled channel values (32 SGPRs) move to vector registers and 112 B spill inside the
     // rank loop; the scalar budget, not the loop form, is what a second item runs into.
+    PSTAMP(2);
     unsigned fcur = 0, fnxt = __builtin_amdgcn_readfirstlane(f0v);
     unsigned fnn = f1v;
     T2 q[4], qn[4];
@@ -871,7 +886,10 @@ profile_item(const FitK& g, const WalkerK* __restrict__ wk, const typename Real<
         lookups(q[s].x, q[s].y);
       }
     }
-    if (!__syncthreads_or(hit)) return;                   // empty sky after all: the flags stay 0
+    PSTAMP(3);
+    const bool anyhit = __syncthreads_or(hit);
+    PSTAMP(4);
+    if (!anyhit) return;                                  // empty sky after all: the flags stay 0
     unsigned m = 0;
 #pragma unroll
     for (int c = 0; c < CH; ++c) m |= (unsigned)(acc[c] != (T)0) << c;
@@ -879,6 +897,7 @@ profile_item(const FitK& g, const WalkerK* __restrict__ wk, const typename Real<
     if ((tid & 63) == 0) s_mask[tid >> 6] = m;
     __syncthreads();
     m = s_mask[0] | s_mask[1] | s_mask[2] | s_mask[3];
+    PSTAMP(5);
     if (tid < CH && kf < g.nv) {
       if ((m >> tid) & 1u) {                              // lit: occupancy byte, and the conv windows this tile feeds
         fl[(long long)kf * ftile] = 1;
@@ -898,6 +917,7 @@ profile_item(const FitK& g, const WalkerK* __restrict__ wk, const typename Real<
       const int k = cix * CH + c;
       if (((m >> c) & 1u) && inb && k < g.nv) out[(long long)k * npx] = acc[c];
     }
+    PSTAMP(6);
   }
 }
 
@@ -4569,7 +4589,7 @@ int slamhip_info(slamhip_ctx* c, int64_t* nleaf, int32_t* wgroup, int32_t* sep) 
 int slamhip_window_shape(slamhip_ctx* c, int32_t* rows, int32_t* cols, int32_t* kpad, int32_t* fold) {
   if (!c) return SLAMHIP_ERR_ARG;
   const bool mom0 = c->k.mom0decon != nullptr;
-  if (rows) *rows = mom0 ? c->ob_ty : (c->fused ? c->fz_sy + 1 : 0);
+  if (rows) *rows = mom0 ? ((c->ob_rows && c->conv_mode != 4) ? 64 : c->ob_ty) : (c->fused ? c->fz_sy + 1 : 0);
   if (cols) *cols = mom0 ? C2_TX : CONV_TX;
   if (kpad) *kpad = c->kpad;
   if (fold) *fold = c->k.fold;
@@ -4972,6 +4992,8 @@ int slamhip_group_counts(slamhip_ctx* c, int nw, int64_t* out) {
     unsigned long long h2[8];
     (void)hipMemcpy(h2, S.livecount + 32, sizeof h2, hipMemcpyDeviceToHost);
     for (int i = 0; i < 8; ++i) fprintf(stderr, "stamp %d %llu\n", i, h2[i]);
+    (void)hipMemcpyFromSymbol(h2, HIP_SYMBOL(g_pstamp), sizeof h2);
+    for (int i = 0; i < 8; ++i) fprintf(stderr, "pstamp %d %llu\n", i, h2[i]);
   }
 #endif
   return SLAMHIP_OK;
