@@ -167,16 +167,19 @@ def test_gpu_sparse_path_equals_dense_on_a_multi_segment_image():
 
 
 @pytest.mark.gpu
-def test_gpu_row_owning_beam_kernel_on_the_observed_grid():
+@pytest.mark.parametrize('npix', [256, 200])
+def test_gpu_row_owning_beam_kernel_on_the_observed_grid(npix):
     """One-term beam of 25..32 padded taps on a square observed grid: the batch path lists the
     64 x 64 windows with emission (k_compact) and runs the row-owning beam kernel on them
     (k_conv_rows<OBS>: only the stored row segments of a staged tile are used).  Against the
     older tile kernel (conv mode 4), the dense direct taps (mode 1) and the single-vector
     product; offsets push emission across window and image edges."""
     from slam_amd import synth
-    fit = synth.make_fit(None, N=256, NV=16, beam_px=(8, 6), scaling='mom0ft')
+    # 200 = three whole windows and one of 8 pixels per axis
+    fit = synth.make_fit(None, N=npix, NV=16, beam_px=(8, 6), scaling='mom0ft')
     try:
         eng = fit.engine
+        assert eng.window_shape()['rows'] == 64 and eng.window_shape()['kpad'] == 32
         P = np.concatenate([synth.walkers(9), synth.walkers(3, workload='dense_disk')])
         P[:, 0] *= 0.3                          # keep the emission inside the 16 channels
         P[1, 8], P[1, 9] = 35.0, -20.0
