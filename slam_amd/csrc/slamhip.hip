@@ -2033,7 +2033,7 @@ __device__ __forceinline__ void row_round(T* tile, const unsigned char* rowlist,
 // pass (which reads every wave's rows) and one after the sums are left.  Same arithmetic, same
 // order of operations per output as k_conv_chi2's fixed-pitch instance: chi2 is bitwise the same.
 template <typename T, bool REGRID, int TY = 64, int KP = 32, bool OBS = false>
-__global__ void __launch_bounds__(CV_NT, KP > 32 ? 2 : sizeof(T) == 4 ? CV_MINW_F32 : 4)   // the 80-tap tile fills a CU's LDS once: 2 waves per SIMD; the float 32-tap one fits three times
+__global__ void __launch_bounds__(CV_NT, KP > 32 ? (sizeof(T) == 4 ? 4 : 2) : sizeof(T) == 4 ? CV_MINW_F32 : 4)   // the 80-tap tile fills a CU's LDS once: 2 waves per SIMD; the float 32-tap one fits three times
 k_conv_rows(FitK g, const T* __restrict__ iunif,
             const int* __restrict__ cellx, const double* __restrict__ fracx,
             const int* __restrict__ celly, const double* __restrict__ fracy,
@@ -4013,7 +4013,7 @@ const void* fused_instance(int variant, bool direct, bool fixed, bool multi = tr
 static bool rows_kernel(const slamhip_ctx* c, int fz_rank) {
   if (fz_rank != 1 || c->conv_mode == 4) return false;
   return (c->fz_variant == 0 && c->sep_fixed) ||
-         (c->fz_variant == 3 && !c->f32 && c->kpad == 80 && c->k.kbeam <= 77);
+         (c->fz_variant == 3 && c->kpad == 80 && c->k.kbeam <= 77);
 }
 
 template <typename T>
@@ -4052,7 +4052,7 @@ void launch_fused(slamhip_ctx* c, Scratch& S, int fz_rank, hipStream_t st, const
     case 1: if (fz_rank) SLAM_FUSED_SEP(64, 3); else SLAM_FUSED(64, 3, true, 0); break;
     case 3:                                                   // one-term beams only (slamhip_create)
       if (rows_kernel(c, fz_rank)) {
-        if constexpr (sizeof(T) == 8) {
+        {
           const int nwin = (int)(c->fz_grid.x * c->fz_grid.y * c->fz_grid.z) * S.wgroup_now;
           hipLaunchKernelGGL((k_conv_rows<T, false, 48, 80>), gz, dim3(CV_NT), fz_lds, st, c->k, (const T*)S.iunif,
                              S.cellx, S.fracx, S.celly, S.fracy, S.livelist, S.livecount, (int)c->fz_grid.x,
@@ -4314,6 +4314,9 @@ int slamhip_create(const slamhip_desc* d, slamhip_ctx** out) {
       fz_tile_bytes(48, c->kpad) / sizeof(double) * c->item + 2 * c->kpad * c->item <= 156 * 1024 &&
       48 + c->kpad - 1 <= 128)
     c->fz_variant = 3;
+  // in float the 64-row tile of such a beam fits a CU once, the 48-row one twice, and the
+  // row-owning kernel has an instance for it
+  if (c->f32 && c->fz_variant == 1 && c->nrank == 1 && c->kpad == 80 && K <= 77) c->fz_variant = 3;
   if (c->sep_variant >= 0) c->sep_lds = sep_lds_bytes(c->sep_variant == 2 ? 32 : 64, c->kpad);
   c->c2d_lds = (size_t)(C2_TY + K - 1) * ((C2_TX + K - 1) | 1) * sizeof(double);
   if (c->sep_lds > 48 * 1024) {   // opt in to large dynamic LDS for the chosen variant only
@@ -4372,6 +4375,12 @@ int slamhip_create(const slamhip_desc* d, slamhip_ctx** out) {
       HIP_TRY(c, hipFuncSetAttribute((const void*)k_conv_rows<double, false, 48, 80>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->fz_lds));
       HIP_TRY(c, hipFuncSetAttribute((const void*)k_conv_rows<double, true, 48, 80>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->fz_lds));
+    }
+    if (c->nrank == 1 && c->fz_variant == 3 && c->f32) {
+      HIP_TRY(c, hipFuncSetAttribute((const void*)k_conv_rows<float, false, 48, 80>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->fz_lds));
+      HIP_TRY(c, hipFuncSetAttribute((const void*)k_conv_rows<float, true, 48, 80>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->fz_lds));
     }
     if (c->nrank >= 1) {
