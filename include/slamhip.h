@@ -229,8 +229,11 @@ int slamhip_beam_rank(slamhip_ctx* ctx);
  * direct taps, 3 = fused kernel without folding the regrid into the beam taps
  * (every walker keeps the convolved tile + bilinear regrid), 4 = as 0 but the
  * phase-by-phase window kernel (k_conv_chi2) where 0 runs the row-owning one
- * (k_conv_rows: one-term beams of 25..32 padded taps in double); both give
- * bitwise the same chi2 (cross-checks). */
+ * (k_conv_rows: one-term beams of 25..32 padded taps, or of 80 with K <= 77, in
+ * double and float; chi2 bitwise the same on 64-row windows, to 1e-12 on 48-row
+ * ones, whose waves split the output rows differently), and with a 'mom0*'
+ * scaling the older tile kernel of the beam pass where 0 lists 64 x 64 windows
+ * for the row-owning one (cross-checks). */
 int slamhip_set_conv_mode(slamhip_ctx* ctx, int mode);
 
 /* Measurement aid (no counterpart in the reference): between _begin and _end
@@ -251,8 +254,11 @@ int slamhip_profile_end(slamhip_ctx* ctx, double* total_ms, int64_t* launches);
  * each run once per tap column), [4] lit (tile, channel) planes
  * of Iunif, [5] stored geometry groups (64 samples x surface), [6] k_profile
  * hits (lane, sample, surface, 16-channel block), [7] the same per 64-sample
- * wave (at least one lane hit).  With a 'mom0*' scaling out[0] is the number of
- * beam windows on the observed grid that held emission and [1]-[3] are 0.
+ * wave (at least one lane hit).  With a 'mom0*' scaling out[0]-[3] describe the
+ * 64 x 64 beam windows on the observed grid that the row-owning kernel ran
+ * (tiles, rows and tap blocks of the regridded cube); where the older tile
+ * kernel runs (rotated beam, rectangular grid, conv mode 4) out[0] is the
+ * number of its windows that held emission and [1]-[3] are 0.
  * bench.py prices the kernels' compulsory bytes and useful FP64 operations
  * from these.  Not available in the dense conv mode (1). */
 int slamhip_group_counts(slamhip_ctx* ctx, int nw, int64_t* out);

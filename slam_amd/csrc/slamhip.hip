@@ -15,11 +15,14 @@
 //   k_profile   : line profile into velocity channels + nested-layer merge ->
 //                 sparse Iunif (only 32x8 tiles with emission) + occupancy bytes
 //   k_compact   : list of conv windows that contain emission
-//   k_conv_chi2 : per window beam convolution in LDS (factorised beam or direct
-//                 taps), bilinear regrid to observed pixels, sum(I*d), sum(I*I)
+//   k_conv_rows / k_conv_chi2 : per window beam convolution in LDS (factorised
+//                 beam: rows owned by waves for one-term beams, else phase by
+//                 phase; or direct taps), regrid to observed pixels (folded into
+//                 the taps where it is a constant shift), sum(I*d), sum(I*I)
 //   k_finalize  : fixed-order partial reduction -> scale, chi2
-// 'mom0*' scalings: k_prep/k_surface/k_profile, k_regrid_mom0, k_conv_obs_sep,
-// k_sum_chi2.  Dense single-vector products (cubemodel, parity taps):
+// 'mom0*' scalings: k_prep/k_surface/k_profile, k_tile_krange, k_mom_model,
+// k_regrid_mom0, then k_compact + k_conv_rows<OBS> on the observed grid (one-term
+// beam, square grid) or k_obs_list + k_conv_obs_live, k_sum_chi2.  Dense single-vector products (cubemodel, parity taps):
 // k_conv_sep / k_conv_2d, k_regrid, k_scale, k_peak_unity.
 #include <hip/hip_runtime.h>
 
@@ -2020,8 +2023,9 @@ __device__ __forceinline__ void row_round(T* tile, const unsigned char* rowlist,
   }
 }
 
-// k_conv_rows: k_conv_chi2's one-term, K + 1 <= 32 taps, 64-row-window case with the window's
-// ROWS OWNED BY WAVES.  k_conv_chi2 walks a window in phases that every wave must finish before
+// k_conv_rows: k_conv_chi2's one-term cases -- K + 1 <= 32 taps on 64-row windows <TY 64, KP 32>,
+// 80 padded taps of a K <= 77 beam on 48-row windows <48, 80>, double or float, and <OBS> for the
+// 'mom0*' scalings' beam on the observed grid -- with the window's ROWS OWNED BY WAVES.  k_conv_chi2 walks a window in phases that every wave must finish before
 // any wave may go on (zero the tile | stage the tiles | row pass | write the intermediate | column
 // pass | sums: five barriers), and the counters show its waves waiting, not computing.  Here a wave
 // owns groups of four image rows (group q of the window belongs to wave (q + q/8) mod 8, so that
