@@ -257,7 +257,7 @@ int slamhip_profile_end(slamhip_ctx* ctx, double* total_ms, int64_t* launches);
  * wave (at least one lane hit).  With a 'mom0*' scaling out[0]-[3] describe the
  * 64 x 64 beam windows on the observed grid that the row-owning kernel ran
  * (tiles, rows and tap blocks of the regridded cube); where the older tile
- * kernel runs (rotated beam, rectangular grid, conv mode 4) out[0] is the
+ * kernel runs (rotated beam, other tap counts, conv mode 4) out[0] is the
  * number of its windows that held emission and [1]-[3] are 0.
  * bench.py prices the kernels' compulsory bytes and useful FP64 operations
  * from these.  Not available in the dense conv mode (1). */

@@ -22,7 +22,7 @@
 //   k_finalize  : fixed-order partial reduction -> scale, chi2
 // 'mom0*' scalings: k_prep/k_surface/k_profile, k_tile_krange, k_mom_model,
 // k_regrid_mom0, then k_compact + k_conv_rows<OBS> on the observed grid (one-term
-// beam, square grid) or k_obs_list + k_conv_obs_live, k_sum_chi2.  Dense single-vector products (cubemodel, parity taps):
+// beam of 25..32 padded taps) or k_obs_list + k_conv_obs_live, k_sum_chi2.  Dense single-vector products (cubemodel, parity taps):
 // k_conv_sep / k_conv_2d, k_regrid, k_scale, k_peak_unity.
 #include <hip/hip_runtime.h>
 
@@ -1198,7 +1198,7 @@ k_compact(FitK g, const unsigned char* __restrict__ winflag, int total,
           const int* __restrict__ tile_ix, const int* __restrict__ tile_jy,
           int wnx, int wny, int sx, int sy, int ty,
           WinDesc* __restrict__ list, int* __restrict__ count, const WalkerK* __restrict__ wk,
-          int split, int nw) {
+          int split, int nw, int nrow_arg) {
   // LIST ORDER.  Thread t is window (channel, window row, block of CV_WB walkers, window column,
   // walker of the block), the walker running fastest: neighbours in the list are the SAME window
   // of the observed cube for up to CV_WB walkers (their `data` pixels are one read from memory
@@ -1254,7 +1254,8 @@ k_compact(FitK g, const unsigned char* __restrict__ winflag, int total,
   const int vcols = CONV_TX + g.kbeam - 1, vrows = ty + g.kbeam - 1;
   const int ftx0 = max(wx0, 0) / PT_X, fty0 = max(wy0, 0) / PT_Y;
   const int fnx = min(wx0 + vcols - 1, n - 1) / PT_X - ftx0 + 1;
-  const int fny = min(wy0 + vrows - 1, n - 1) / PT_Y - fty0 + 1;
+  const int nrow = nrow_arg ? nrow_arg : n;               // (the observed grid of the 'mom0*' path may be rectangular)
+  const int fny = min(wy0 + vrows - 1, nrow - 1) / PT_Y - fty0 + 1;
   // The descriptor is assembled in its slot of the list; the bitmaps are kept in
   // named registers (static word indices) so that nothing lives in scratch.
   WinDesc* D = &list[slot];
@@ -2047,7 +2048,7 @@ k_conv_rows(FitK g, const T* __restrict__ iunif,
             const T* __restrict__ gxw, const T* __restrict__ gyw, int tail4_arg, int rev_total,
             const unsigned char* __restrict__ rowflag = nullptr) {
   // OBS (the 'mom0*' scalings' batch path): `iunif` is the regridded, moment-scaled cube on the
-  // observed grid itself (g.nneed = nx = ny in the FitK copy this launch gets), windows tile it
+  // observed grid itself (g.nneed = nx in the FitK copy this launch gets, g.ny its rows), windows tile it
   // without overlap, plain beam taps, and a window leaves sum (data - model)^2 over its pixels
   // (NaN terms dropped, :601) in partial[e].  k_regrid_mom0 stored only the 64-pixel row
   // segments it marked in `rowflag`: what a staged tile holds outside them is stale and is
@@ -2079,6 +2080,7 @@ k_conv_rows(FitK g, const T* __restrict__ iunif,
   __shared__ double sg[CV_NW], sf[CV_NW];
   const bool tail4 = tail4_arg != 0;
   const int K = g.kbeam, ng = g.ngauss, n = g.nneed;
+  const int nrow = OBS ? g.ny : n;                          // image rows (n = its columns and row pitch)
   const int vrows = TY + K - 1, vcols = TX + K - 1;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -2164,7 +2166,7 @@ k_conv_rows(FitK g, const T* __restrict__ iunif,
     const int tb = head(7);
     const int tby = (tb >> 8) & 0xff, tbx = tb & 0xff;
     const int wi = (int)((unsigned)tb >> 16), k = z - wi * g.nv;
-    const T* src = iunif + (long long)z * n * n;
+    const T* src = iunif + (long long)z * nrow * n;
     const int x0 = tbx * (OBS ? TX : TX - 1), y0 = tby * (OBS ? TY : TY - 1);
     const int wx0 = x0 - ng, wy0 = y0 - ng;
     const int ftx0 = max(wx0, 0) / PT_X, fty0 = max(wy0, 0) / PT_Y;
@@ -2230,12 +2232,12 @@ k_conv_rows(FitK g, const T* __restrict__ iunif,
       }
       uocc |= rowocc << (NFX * gi);
       const int r = rb + srow, irow = 4 * Q + srow;
-      const unsigned lanem = (r >= 0 && r < vrows && irow < n) ? (colm & rowocc) : 0u;
+      const unsigned lanem = (r >= 0 && r < vrows && irow < nrow) ? (colm & rowocc) : 0u;
       sok |= lanem << (NFX * gi);
       const T* rp = src + ((long long)irow * n + (ftx0 * PT_X + scol));
       if constexpr (OBS) {
         if (rowocc && lanem) {
-          const unsigned char* rf = rowflag + ((long long)z * n + irow) * nseg + seg0;
+          const unsigned char* rf = rowflag + ((long long)z * nrow + irow) * nseg + seg0;
 #pragma unroll
           for (int j = 0; j < 3; ++j)
             if (seg0 + j < nseg && rf[j]) segm |= 1u << (4 * gi + j);
@@ -3908,7 +3910,7 @@ int run_group_mom0(slamhip_ctx* c, Scratch& S, const double* d_params, int nw, d
     return SLAMHIP_OK;
   }
   if (c->ob_ty && c->ob_rows && !d_model && c->conv_mode != 1 && c->conv_mode != 4) {
-    // batch path, one-term beam of <= 32 padded taps on a square observed grid: the windows with
+    // batch path, one-term beam of 25..32 padded taps, observed rows of even length: the windows with
     // emission listed with their tile bitmaps (k_compact, as for the 'uniform' scaling), then
     // the row-owning beam kernel on them; conv mode 4 keeps the older tile kernel below
     const int nwin = nw * k.nv * c->ob_wnx * c->ob_wny;
@@ -3919,7 +3921,7 @@ int run_group_mom0(slamhip_ctx* c, Scratch& S, const double* d_params, int nw, d
       HIP_TRY(c, hipMemsetAsync(c->d_ocount, 0, LIVECOUNT_WORDS * sizeof(int), st));
       hipLaunchKernelGGL(k_compact, dim3(compact_blocks(nwin, nw)), dim3(256), 0, st, ko, c->d_owin, nwin,
                          c->d_oflags, c->ob_ftx, c->ob_fty, (const int*)nullptr, (const int*)nullptr,
-                         c->ob_wnx, c->ob_wny, CONV_TX, 64, 64, c->d_odesc, c->d_ocount, S.wk, 0, nw);
+                         c->ob_wnx, c->ob_wny, CONV_TX, 64, 64, c->d_odesc, c->d_ocount, S.wk, 0, nw, k.ny);
     }
     {
       Timed t_(c, KID_CONV, st);
@@ -4089,7 +4091,7 @@ int run_group(slamhip_ctx* c, Scratch& S, const double* d_params, int nw, double
       hipLaunchKernelGGL(k_compact, dim3(compact_blocks(nwin, nw)), dim3(256), 0, st, c->k, S.winflag, nwin,
                          S.flags, c->ftx, c->fty, S.tile_ix, S.tile_jy,
                          (int)c->fz_grid.x, (int)c->fz_grid.y, c->fz_sx, c->fz_sy, c->fz_sy + 1,
-                         S.livelist, S.livecount, S.wk, rows_kernel(c, fz_rank) ? 1 : 0, nw);
+                         S.livelist, S.livecount, S.wk, rows_kernel(c, fz_rank) ? 1 : 0, nw, 0);
       S.wgroup_now = nw;
     }
     {
@@ -4566,9 +4568,9 @@ int slamhip_create(const slamhip_desc* d, slamhip_ctx** out) {
       c->ob_persist = pr.multiProcessorCount * per;
     }
     // the row-owning batch path: one-term beam, 32 padded taps (the 64-row tile twice per CU),
-    // square observed grid of even size (the kernels index one `n`, and stage pixel pairs)
+    // observed rows of even length (the kernel stages aligned pixel pairs)
     if (c->d_oblist && c->nrank == 1 && c->fz_variant == 0 && c->kpad == 32 && !c->f32 &&
-        k.nx == k.ny && k.nx % 2 == 0 && k.nx >= 64) {
+        k.nx % 2 == 0 && k.nx >= 64) {
       c->ob_wnx = (k.nx + 63) / 64;
       c->ob_wny = (k.ny + 63) / 64;
       c->ob_ftx = (k.nx + PT_X - 1) / PT_X;

@@ -356,3 +356,33 @@ def test_weighted_quantile_rule():
     assert q[0] == 1.0 and q[1] == pytest.approx(2.0) and q[3] == 4.0
     assert q[2] == pytest.approx(2.0 + (0.5 - 0.4 / 0.9) / (0.4 / 0.9))
     assert utils.weighted_quantile(x, [0.5]) == [2.5]
+
+
+def test_bench_quotes_measured_traffic_only_for_the_build_it_was_measured_on():
+    """bench.py's roofline.traffic comes from the committed PMC profile: with the library's
+    sources unchanged since the profile it is a number for the beam kernel (whatever instance
+    name the kernel has in the profile), otherwise None with the reason -- never stale bytes."""
+    import json
+    import os
+    import bench
+    from slam_amd import build
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prof = json.load(open(os.path.join(root, 'profiles', bench.TRAFFIC_PROFILE)))
+    meta = prof['_meta']
+
+    class Args:
+        config, bpa, scaling, workload, dtype = (meta['config'], meta['bpa'], meta['scaling'],
+                                                 meta['workload'], meta['dtype'])
+        walkers = 8 * meta['walkers_per_launch']
+
+    class Eng:
+        walkers_per_group = meta['walkers_per_launch']
+
+    got, why = bench.measured_traffic('k_conv', Args, Eng)
+    if meta['src_sha'] == build.src_sha('slamhip'):
+        assert got is not None and 1e9 < got < 1e11, why
+        assert bench.measured_traffic('k_profile', Args, Eng)[0] is not None
+    else:
+        assert got is None and 'stale profile' in why
+    Args.workload = 'dense_disk'
+    assert bench.measured_traffic('k_conv', Args, Eng)[0] is None

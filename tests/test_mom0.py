@@ -206,6 +206,41 @@ def test_gpu_row_owning_beam_kernel_on_the_observed_grid(npix):
         fit.close()
 
 
+@pytest.mark.gpu
+def test_gpu_row_owning_beam_kernel_on_a_rectangular_grid():
+    """The same on a 256 x 176 pixel cube (rows cut from a square synthetic one): the observed
+    grid's rows and columns are told apart in the window list, the staging and the sums."""
+    from slam_amd import synth
+    from slam_amd.channelfit import ChannelFit
+    sq = synth.make_fit(None, N=256, NV=16, beam_px=(8, 6), scaling='mom0ft')
+    x, y, v, data = sq.x.copy(), sq.y[40:216].copy(), sq.v.copy(), sq.data[:, 40:216, :].copy()
+    bmaj, bmin, bpa, sigma = sq.bmaj, sq.bmin, sq.bpa, sq.sigma
+    sq.close()
+    fit = ChannelFit(scaling='mom0ft', progressbar=False)
+    fit.set_cube(x, y, v, data, bmaj, bmin, bpa, sigma)
+    quiet(fit.makegrid, cubefits=None, pa=2.0, incl=60.0, rmax=synth.RMAX, signmajor=1, signminor=1)
+    try:
+        eng = fit.engine
+        assert (eng.nx, eng.ny) == (256, 176) and eng.window_shape()['rows'] == 64
+        P = synth.walkers(8)
+        P[:, 0] *= 0.3
+        P[1, 8], P[1, 9] = 35.0, -60.0
+        P[2, 1] = 400.0
+        chi2 = fit.chi2_batch(P)
+        assert eng.group_counts(len(P))['window_rows'] > 0
+        assert np.all(np.isfinite(chi2)) and len(set(chi2.tolist())) == len(P)
+        eng.set_conv_mode(4)
+        tile = fit.chi2_batch(P)
+        eng.set_conv_mode(1)
+        dense = fit.chi2_batch(P)
+        eng.set_conv_mode(0)
+        np.testing.assert_allclose(chi2, tile, rtol=1e-11)
+        np.testing.assert_allclose(chi2, dense, rtol=1e-11)
+        assert np.array_equal(fit.chi2_batch(P[::-1])[::-1], chi2)
+    finally:
+        fit.close()
+
+
 # ---------------------------------------------------------------------------
 # Moment maps behind plotmom (SURVEY.md 8f-4): golden vectors recorded from the
 # reference's makemom01 by tests/golden/make_golden_moments.py.
